@@ -1,0 +1,79 @@
+"""Scenario geometry and parameter presets (host side, pure Python).
+
+Everything here restates constants of the reference so that a scenario is the same world the
+reference builds; citations are into /root/reference/collision_avoidance/ (env.py =
+envs/collision_avoidence_env.py, ALAN = ALAN/ALAN_true.py).
+"""
+from math import pi, sqrt
+
+SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY = 0, 1, 2
+SCENARIO_IDS = {"crowd": SCN_CROWD, "circle": SCN_CIRCLE, "doorway": SCN_DOORWAY}
+
+DONE_XLESS, DONE_GOAL, DONE_REGOAL = 0, 1, 2
+
+
+def _rect(upper_left, upper_right, bottom_right, bottom_left):
+    """env.py:143-149 / ALAN:474-480: an obstacle is the 4-vertex polygon in the given order."""
+    return [upper_left, upper_right, bottom_right, bottom_left]
+
+
+def crowd_envsize(n_agents, radius=0.5):
+    """ALAN:272"""
+    return sqrt(2 * radius * n_agents) * 2
+
+
+def circle_envsize(n_agents, radius=0.5):
+    """ALAN:299-301"""
+    return 2 * (radius * 3 * n_agents / (2 * pi)) + 4 * radius
+
+
+def obstacles(scenario, n_agents, radius=0.5):
+    """Obstacle polygons of a scenario as lists of (x, y)."""
+    if scenario in ("crowd", SCN_CROWD):
+        e = crowd_envsize(n_agents, radius)
+        return [_rect((0.0, 0.0), (0.0, e), (e, e), (e, 0.0))]          # ALAN:291-292
+    if scenario in ("circle", SCN_CIRCLE):
+        e = circle_envsize(n_agents, radius)
+        return [_rect((0.0, 0.0), (0.0, e), (e, e), (e, 0.0))]          # ALAN:327-328
+    if scenario in ("doorway", SCN_DOORWAY):
+        e = 10                                                            # env.py:41
+        return [_rect((-15.0, 0.0), (-15.0, e), (e, e), (e, 0.0)),       # env.py:118
+                _rect((2.0, 0.0), (2.5, 0.0), (2.5, 4.4), (2.0, 4.4)),   # env.py:121
+                _rect((2.0, 5.6), (2.5, 5.6), (2.5, 10.0), (2.0, 10.0))]  # env.py:122
+    raise ValueError("unknown scenario %r" % (scenario,))
+
+
+def env_params():
+    """The reference env's constants (env.py:27-44, 130, 359, 396, 478)."""
+    return dict(time_step=1 / 60., neighbor_dist=1.5, max_neighbors=5, time_horizon=1.5,
+                time_horizon_obst=1.5, radius=0.5, max_speed=1.0, max_step=1000,
+                done_mode=DONE_XLESS, done_x_thresh=2.0, reward_scale=0.3,
+                spawn_x0=5.0, spawn_x1=10.0, spawn_y0=0.0, spawn_y1=10.0,
+                goal_x0=0.0, goal_x1=10.0, goal_y0=0.0, goal_y1=10.0)
+
+
+def alan_params(n_agents, scenario="crowd"):
+    """The ALAN simulator's constants (ALAN:15-20, 47, 59)."""
+    e = crowd_envsize(n_agents) if scenario == "crowd" else circle_envsize(n_agents)
+    return dict(time_step=1 / 60., neighbor_dist=5.0, max_neighbors=10, time_horizon=1.5,
+                time_horizon_obst=1.5, radius=0.5, max_speed=1.0,
+                max_step=int((10 / (1 / 60.)) * n_agents), done_mode=DONE_GOAL, done_x_thresh=2.0,
+                reward_scale=0.6, spawn_x0=0.0, spawn_x1=e, spawn_y0=0.0, spawn_y1=e,
+                goal_x0=0.0, goal_x1=e, goal_y0=0.0, goal_y1=e)
+
+
+def bench_params(n_agents, neighbor_dist, max_neighbors):
+    """Synthetic random start/goal workload of SURVEY.md section 8d: the ALAN crowd recipe with a
+    new goal drawn whenever one is reached, no episode cap."""
+    p = alan_params(n_agents, "crowd")
+    p.update(neighbor_dist=neighbor_dist, max_neighbors=max_neighbors, done_mode=DONE_REGOAL,
+             max_step=0, reward_scale=0.3)
+    return p
+
+
+BENCH_CONFIGS = {
+    # BASELINE.json configs[1..4]
+    "C2": dict(n_arenas=1024, n_agents=16, neighbor_dist=1.5, max_neighbors=5),
+    "C3": dict(n_arenas=4096, n_agents=64, neighbor_dist=5.0, max_neighbors=10),
+    "C5": dict(n_arenas=256, n_agents=512, neighbor_dist=5.0, max_neighbors=10),
+}

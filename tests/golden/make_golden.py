@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference's own Python.
+
+Runs only where /root/reference exists (the build container); the reference never travels and
+none of its source is copied: the fixtures hold inputs and the outputs the reference computed.
+
+  utils_vectors.npz   utils.py:5-40 line_intersection and utils.py:42-113 comp_laser on random
+                      and edge-case inputs.
+  env_doorway_*.npz   collision_avoidence_env.py Collision_Avoidance_Env driven through
+                      __init__/reset/step/orca_step with the third-party `rvo2` module replaced
+                      by oracle/rvo2_shim.py (the oracle's ORCA), `gym`, `ray`, `tkinter` stubbed,
+                      time.clock/time.sleep shimmed and random.uniform replaced by a seeded
+                      stream.  Pins the env loop A5-A9, A16-A19.
+  alan_scenarios.npz  ALAN_true.py scenario generators (circle, crowd) start/goal layouts.
+
+Usage: python tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+
+def load_ref_utils():
+    spec = importlib.util.spec_from_file_location(
+        "ref_utils", os.path.join(REF, "collision_avoidance/envs/utils.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def gen_utils_vectors():
+    u = load_ref_utils()
+    rng = np.random.RandomState(1234)
+    # --- line_intersection: random + edge cases probed in SURVEY section 4 ---
+    L1, L2 = [], []
+    for _ in range(400):
+        ray = ((0.0, 0.0), tuple(rng.uniform(-2, 2, 2)))
+        seg = (tuple(rng.uniform(-2, 2, 2)), tuple(rng.uniform(-2, 2, 2)))
+        L1.append(ray); L2.append(seg)
+    for _ in range(100):   # general p0 too
+        L1.append((tuple(rng.uniform(-1, 1, 2)), tuple(rng.uniform(-2, 2, 2))))
+        L2.append((tuple(rng.uniform(-2, 2, 2)), tuple(rng.uniform(-2, 2, 2))))
+    edge = [
+        (((0, 0), (1.5, 0)), ((0, 1), (3, 1))),          # parallel
+        (((0, 0), (1.5, 0)), ((1.5, -1), (1.5, 1))),     # hit exactly at the ray tip (t = 1)
+        (((0, 0), (1.5, 0)), ((1.0, 0.0), (1.0, 1.0))),  # segment endpoint on the ray
+        (((0, 0), (1.5, 0)), ((0.0, -1.0), (0.0, 1.0))), # segment through the origin -> d = 0
+        (((0, 0), (1.5, 0)), ((-1.0, -1.0), (-1.0, 1.0))),  # behind
+        (((0, 0), (1.5, 0)), ((1.0, 1.0), (1.0, -1.0))), # reversed orientation (denom < 0)
+        (((0, 0), (1.5, 0)), ((0.5, 0.0), (1.0, 0.0))),  # collinear overlapping
+        (((0, 0), (1.5, 0)), ((1.6, -1), (1.6, 1))),     # just beyond the tip
+    ]
+    for a, b in edge:
+        L1.append(a); L2.append(b)
+    li_in = np.array([[a[0][0], a[0][1], a[1][0], a[1][1], b[0][0], b[0][1], b[1][0], b[1][1]]
+                      for a, b in zip(L1, L2)], np.float64)
+    li_out = []
+    for a, b in zip(L1, L2):
+        d, p = u.line_intersection(a, b)
+        li_out.append([d, p[0], p[1]])
+    li_out = np.array(li_out, np.float64)
+
+    # --- comp_laser: the reference env's own ray table and octagon are rebuilt here from the
+    # formulas' constants (nd = 1.5, 16 rays; r = 0.5, 8 chords) with the reference's math calls
+    from math import cos, sin, pi
+    nd, nr = 1.5, 16
+    rays = [((0, 0), (nd * cos(i * 2 * pi / nr), -nd * sin(i * 2 * pi / nr))) for i in range(nr)]
+    cases_segs, cases_orient, cases_out = [], [], []
+
+    def octagon(rel, r=0.5, n=8):
+        pts = [(r * cos(i * 2 * pi / n), -r * sin(i * 2 * pi / n)) for i in range(n)]
+        return [((pts[i][0] + rel[0], pts[i][1] + rel[1]),
+                 (pts[(i + 1) % n][0] + rel[0], pts[(i + 1) % n][1] + rel[1])) for i in range(n)]
+
+    def run_case(lines_with_vel, orient):
+        res = u.comp_laser(rays, lines_with_vel, orient)
+        out = np.array([[r[0][0], r[0][1], r[1][0], r[1][1]] for r in res], np.float64)
+        segs = np.array([[l[0][0][0], l[0][0][1], l[0][1][0], l[0][1][1], l[1][0], l[1][1]]
+                         for l in lines_with_vel], np.float64)
+        cases_segs.append(segs); cases_orient.append(orient); cases_out.append(out)
+
+    # the worked example of SURVEY section 8c
+    lw = [(s, (0.2, -0.4)) for s in octagon((1.0, 0.3))] + [(((-0.7, -3.0), (-0.7, 3.0)), (0, 0))]
+    run_case(lw, (0.6, 0.8))
+    for _ in range(60):
+        lw = []
+        for _k in range(rng.randint(1, 6)):
+            ang, dist = rng.uniform(0, 2 * pi), rng.uniform(0.2, 1.9)
+            vel = tuple(rng.uniform(-1, 1, 2))
+            lw += [(s, vel) for s in octagon((dist * cos(ang), dist * sin(ang)))]
+        for _k in range(rng.randint(0, 3)):
+            p = rng.uniform(-2, 2, 4)
+            lw.append((((p[0], p[1]), (p[2], p[3])), (0, 0)))
+        th = rng.uniform(0, 2 * pi)
+        run_case(lw, (cos(th), sin(th)))
+    # segment through the origin: d = 0, hit (0,0) -> reported as a miss (utils.py:103)
+    run_case([(((0.0, -1.0), (0.0, 1.0)), (0.3, 0.3)), (((1.0, -1.0), (1.0, 1.0)), (0.1, 0.2))], (1.0, 0.0))
+    m = max(s.shape[0] for s in cases_segs)
+    segs = np.zeros((len(cases_segs), m, 6)); counts = np.zeros(len(cases_segs), np.int32)
+    for i, s in enumerate(cases_segs):
+        segs[i, :s.shape[0]] = s; counts[i] = s.shape[0]
+    np.savez_compressed(os.path.join(HERE, "utils_vectors.npz"),
+                        li_in=li_in, li_out=li_out,
+                        rays=np.array([r[1] for r in rays], np.float64),
+                        cl_segs=segs, cl_counts=counts,
+                        cl_orient=np.array(cases_orient, np.float64),
+                        cl_out=np.array(cases_out, np.float64))
+    print("utils_vectors.npz: %d line_intersection, %d comp_laser cases" % (len(li_in), len(cases_out)))
+
+
+# ---------------------------------------------------------------------------------------------
+class _Stream:
+    """Seeded replacement for random.uniform; records what it hands out."""
+
+    def __init__(self, seed, box=None):
+        self.rng = np.random.RandomState(seed)
+        self.box = box
+
+    def __call__(self, a, b):
+        return float(a + (b - a) * self.rng.random_sample())
+
+
+def install_stubs():
+    from oracle import rvo2_shim
+    gym = types.ModuleType("gym")
+
+    class Env(object):
+        pass
+
+    class Box(object):
+        def __init__(self, low, high, shape):
+            self.low, self.high, self.shape = low, high, shape
+
+    gym.Env = Env
+    gym.spaces = types.ModuleType("gym.spaces"); gym.spaces.Box = Box
+    gym.utils = types.ModuleType("gym.utils")
+    seeding = types.ModuleType("gym.utils.seeding")
+    seeding.np_random = lambda seed=None: (np.random.RandomState(seed), seed)
+    gym.utils.seeding = seeding
+    gym.envs = types.ModuleType("gym.envs")
+    reg = types.ModuleType("gym.envs.registration"); reg.register = lambda **kw: None
+    gym.envs.registration = reg
+    for name, mod in [("gym", gym), ("gym.spaces", gym.spaces), ("gym.utils", gym.utils),
+                      ("gym.utils.seeding", seeding), ("gym.envs", gym.envs),
+                      ("gym.envs.registration", reg)]:
+        sys.modules[name] = mod
+    ray = types.ModuleType("ray")
+    for n in ("ray.rllib", "ray.rllib.env", "ray.rllib.env.multi_agent_env"):
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["ray"] = ray
+
+    class MultiAgentEnv(object):
+        pass
+
+    sys.modules["ray.rllib.env.multi_agent_env"].MultiAgentEnv = MultiAgentEnv
+    tk = types.ModuleType("tkinter")
+
+    class _Widget(object):
+        def __init__(self, *a, **k):
+            self._n = 0
+
+        def __getattr__(self, name):
+            def f(*a, **k):
+                self._n += 1
+                return self._n
+            return f
+
+    tk.Tk = _Widget; tk.Canvas = _Widget; tk.LAST = "last"
+    tk.__all__ = ["Tk", "Canvas", "LAST"]
+    sys.modules["tkinter"] = tk
+    rv = types.ModuleType("rvo2"); rv.PyRVOSimulator = rvo2_shim.PyRVOSimulator
+    sys.modules["rvo2"] = rv
+    if not hasattr(time, "clock"):
+        time.clock = time.perf_counter
+    time.sleep = lambda s: None
+    sys.path.insert(0, REF)
+
+
+def sim_state(env):
+    n = env.numAgents
+    pos = np.array([env.sim.getAgentPosition(i) for i in range(n)], np.float32)
+    vel = np.array([env.sim.getAgentVelocity(i) for i in range(n)], np.float32)
+    pref = np.array([env.sim.getAgentPrefVelocity(i) for i in range(n)], np.float32)
+    tgt = np.array(env.world["targets_pos"], np.float64)
+    return pos, vel, pref, tgt
+
+
+def obs_array(env, d):
+    return np.array([d['agent_%d' % i] for i in range(env.numAgents)], np.float64)
+
+
+def gen_env_fixture(name, n_agents, seed, n_steps, reset_at, obs_every, spawn_squeeze=None):
+    import warnings
+    warnings.simplefilter("ignore")
+    import collision_avoidance.envs.collision_avoidence_env as refenv
+    stream = _Stream(seed)
+    if spawn_squeeze is not None:
+        # still a legal outcome of uniform(a, b): draws are squeezed towards the doorway so that
+        # walls, the door gap and neighbours are all exercised within a short run
+        base = stream
+
+        def squeezed(a, b):
+            u = base.rng.random_sample()
+            lo, hi = spawn_squeeze.get((a, b), (0.0, 1.0))
+            return float(a + (b - a) * (lo + (hi - lo) * u))
+        refenv.uniform = squeezed
+    else:
+        refenv.uniform = stream
+    import io
+    import contextlib
+    env = refenv.Collision_Avoidance_Env(numAgents=n_agents)
+    rng = np.random.RandomState(seed + 1)
+    rec = dict(actions=[], pos=[], vel=[], pref=[], tgt=[], reward=[], done_all=[], agents_done=[],
+               obs=[], obs_steps=[], reset_steps=[], reset_pos=[], reset_obs=[], kind=[])
+    p, v, pf, t = sim_state(env)
+    init = dict(pos0=p, vel0=v, pref0=pf, tgt0=t, obs0=obs_array(env, env.gym_obs))
+    for s in range(n_steps):
+        if s in reset_at:
+            with contextlib.redirect_stdout(io.StringIO()):
+                o = env.reset()
+            p, v, pf, t = sim_state(env)
+            rec["reset_steps"].append(s); rec["reset_pos"].append(p); rec["reset_obs"].append(obs_array(env, o))
+        kind = 0
+        if s % 17 == 16:
+            kind = 1  # an orca_step (env.py:447-458) in between
+            with contextlib.redirect_stdout(io.StringIO()):
+                env.orca_step((0, 0))
+            act = np.zeros(n_agents, np.float32)
+            rew = np.zeros(n_agents)
+            done_all = False
+            o = env.gym_obs
+        else:
+            act = rng.uniform(-np.pi, np.pi, n_agents).astype(np.float32) * (0.35 if s % 3 else 1.0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                o, r, d, _ = env.step({'agent_%d' % i: act[i:i + 1] for i in range(n_agents)})
+            rew = np.array([float(r['agent_%d' % i]) for i in range(n_agents)], np.float64)
+            done_all = bool(d['__all__'])
+        p, v, pf, t = sim_state(env)
+        rec["kind"].append(kind); rec["actions"].append(act); rec["pos"].append(p); rec["vel"].append(v)
+        rec["pref"].append(pf); rec["tgt"].append(t); rec["reward"].append(rew)
+        rec["done_all"].append(done_all); rec["agents_done"].append(np.array(env.agents_done, np.int32))
+        if s % obs_every == 0 or s < 24 or kind == 1:
+            rec["obs"].append(obs_array(env, o)); rec["obs_steps"].append(s)
+    out = {k: np.array(v) for k, v in rec.items()}
+    out.update(init)
+    out["n_agents"] = np.int32(n_agents)
+    out["step_count_final"] = np.int32(env.step_count)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    nz = int((np.abs(out["obs"]) > 0).sum())
+    print("%s: %d steps, %d obs snapshots (%d non-zero obs entries), done_all any=%s"
+          % (name, n_steps, len(rec["obs_steps"]), nz, bool(np.any(out["done_all"]))))
+
+
+def gen_alan_scenarios():
+    import warnings
+    warnings.simplefilter("ignore")
+    import collision_avoidance.ALAN.ALAN_true as alan
+    out = {}
+    for scen, n in (("circle", 8), ("circle", 100), ("crowd", 16)):
+        alan.uniform = _Stream(77)
+        sim = alan.Collision_Avoidance_Sim(numAgents=n, scenario=scen, visualize=False)
+        pos = np.array([sim.sim.getAgentPosition(i) for i in range(n)], np.float32)
+        tgt = np.array([sim.world["targets_pos"][i][0] for i in range(n)], np.float64)
+        out["%s%d_pos" % (scen, n)] = pos
+        out["%s%d_goal" % (scen, n)] = tgt
+        out["%s%d_envsize" % (scen, n)] = np.float64(sim.envsize)
+        out["%s%d_max_step" % (scen, n)] = np.int32(sim.max_step)
+    np.savez_compressed(os.path.join(HERE, "alan_scenarios.npz"), **out)
+    print("alan_scenarios.npz:", sorted(out))
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        print("reference not present; nothing to do")
+        sys.exit(0)
+    gen_utils_vectors()
+    install_stubs()
+    gen_env_fixture("env_doorway_n10.npz", 10, seed=7, n_steps=420, reset_at=(200,), obs_every=6)
+    gen_env_fixture("env_doorway_n6_dense.npz", 6, seed=11, n_steps=260, reset_at=(130,), obs_every=4,
+                    spawn_squeeze={(5.0, 10): (0.0, 0.25), (0, 10): (0.3, 0.7)})
+    gen_alan_scenarios()
