@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-steps/s of the batched collision-avoidance step on MI355X.
+
+One "step" = one pass of the hot path over every arena of the workload: the full environment
+step of the reference (collision_avoidence_env.py:367-416: action -> preferred velocity ->
+ORCA doStep -> reward -> done test -> 16-ray laser observation) for 4096 arenas x 64 agents per
+GPU (BASELINE.json configs[2], "C3": random start/goal crowd, neighborDist 5, maxNeighbors 10),
+state and actions resident in HBM.  value = agents advanced per second over all GPUs.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2|C5] [--mode step|orca]
+                  [--no-cpu-baseline]
+N > 1: launched by torch.distributed.run, one rank per GPU; arenas are sharded (no data-path
+collective: arenas never interact), one RCCL all_gather of the per-rank statistics at the end.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# algorithmic bytes per agent-step
+BYTES_STEP_KERNEL_FULL = 60   # read pos 8 vel 8 goal 8 done 4 action 4; write pos 8 vel 8 done 4 stat 4 reward 4
+BYTES_STEP_KERNEL_ORCA = 52
+BYTES_OBS_KERNEL = 256        # the 64-float observation row
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C5"])
+    ap.add_argument("--mode", default="step", choices=["step", "orca"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(workload, mode, seconds):
+    """The CPU oracle (a serial C++ restatement of the same path, 1 core) on a bounded sample of
+    the same workload: 64 arenas of the same scenario, stepped until `seconds` have elapsed."""
+    from collision_avoidance_amd import scenarios
+    from oracle import oracle as o
+    from tests import helpers as H
+    w = scenarios.BENCH_CONFIGS[workload]
+    N = w["n_agents"]
+    A = max(1, min(64, 4096 // N))
+    p = scenarios.bench_params(N, w["neighbor_dist"], w["max_neighbors"])
+    env = H.make_oracle(A, N, "crowd", p, seed=0)
+    rng = np.random.RandomState(0)
+    acts = rng.uniform(-0.5, 0.5, (8, A, N)).astype(np.float32)
+    for s in range(3):
+        env.step(acts[s], flags=o.F_OBS) if mode == "step" else env.orca_step(flags=0)
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < seconds:
+        for s in range(5):
+            if mode == "step":
+                env.step(acts[(steps + s) % 8], flags=o.F_OBS)
+            else:
+                env.orca_step(flags=0)
+        steps += 5
+    dt = time.perf_counter() - t0
+    return {"value": A * N * steps / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d arenas x %d agents x %d steps of the same workload (%s mode), oracle/ca_oracle.cpp "
+                      "-O2 serial, %.1f s" % (A, N, steps, mode, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from collision_avoidance_amd import build as _b
+    if rank == 0 and not os.path.exists(_b.LIB_PATH):  # normally prebuilt by __graft_entry__.build()
+        _b.build()
+    if dist is not None:
+        dist.barrier()
+    from collision_avoidance_amd import scenarios
+    from collision_avoidance_amd.vec_env import VecCollisionAvoidanceEnv
+    from collision_avoidance_amd import _lib
+
+    w = scenarios.BENCH_CONFIGS[args.workload]
+    A, N = w["n_arenas"], w["n_agents"]
+    p = scenarios.bench_params(N, w["neighbor_dist"], w["max_neighbors"])
+    env = VecCollisionAvoidanceEnv(A, N, scenario="crowd", params=p, device=local, seed=0,
+                                   arena_offset=rank * A, use_torch=True)
+    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    pool = (torch.rand((16, A, N), device="cuda", generator=gen) - 0.5)  # actions in [-0.5, 0.5] rad
+    full = args.mode == "step"
+
+    def one_step(i, evs=None):
+        if full:
+            if evs:
+                evs[0].record()
+            env._call("ca_step", env.h, pool[i % 16].data_ptr(), _lib.F_STATS)
+            if evs:
+                evs[1].record()
+            env._call("ca_observe", env.h)
+            if evs:
+                evs[2].record()
+        else:
+            if evs:
+                evs[0].record()
+            env._call("ca_orca_step", env.h, _lib.F_STATS)
+            if evs:
+                evs[1].record()
+
+    for i in range(args.warmup):
+        one_step(i)
+    nev = 3 if full else 2
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(nev)] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i, events[i])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    k_step = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))  # ms
+    k_obs = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if full else 0.0
+    st = env.stats()
+    stats_vec = torch.tensor([st["agent_steps"], st["episodes"], st["collisions"], st["obst_collisions"],
+                              st["goals_reached"], st["obst_overflow"]], device="cuda", dtype=torch.int64)
+    if dist is not None:  # the single collective of the job: per-rank episode statistics over RCCL
+        gathered = [torch.zeros_like(stats_vec) for _ in range(world)]
+        dist.all_gather(gathered, stats_vec)
+        stats_vec = torch.stack(gathered).sum(0)
+    if rank == 0:
+        agents = A * N
+        value = world * agents * args.steps / dt
+        if full and k_obs >= k_step:
+            dom, kms, kbytes = "obs_kernel", k_obs, BYTES_OBS_KERNEL
+        else:
+            dom, kms, kbytes = "step_kernel", k_step, (BYTES_STEP_KERNEL_FULL if full else BYTES_STEP_KERNEL_ORCA)
+        achieved = agents * kbytes / (kms * 1e-3) / 1e9
+        out = {
+            "metric": "agent-steps/sec (whole node), %d arenas x %d agents per GPU" % (A, N),
+            "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d arenas x %d agents per GPU, random start/goal crowd (ALAN recipe), "
+                                   "neighborDist %.1f, maxNeighbors %d, %s" %
+                                   (args.workload, A, N, w["neighbor_dist"], w["max_neighbors"],
+                                    "full env step (action -> ORCA -> reward/done -> laser obs)" if full
+                                    else "ORCA-only step (no observation)"),
+                       "mode": args.mode, "sharding": "arenas, %d per GPU" % A},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_agent": kbytes, "kernel_ms": kms},
+            "kernels_ms": {"step_kernel": k_step, "obs_kernel": k_obs},
+            "stats": dict(zip(["agent_steps", "episodes", "collisions", "obst_collisions",
+                               "goals_reached", "obst_overflow"], [int(v) for v in stats_vec.tolist()])),
+            "launch": env.launch_info(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.mode, args.cpu_seconds)
+        print(json.dumps(out))
+    env.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,41 @@
+"""Builds collision_avoidance_amd/libcaenv.so (HIP, gfx950 only) in-tree with hipcc."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcaenv.so")
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("ca_env.hip", "ca_kernels.h", "ca_math.h")] + \
+          [os.path.join(os.path.dirname(_HERE), "include", "ca_env.h")]
+# -ffp-contract=off: no FMA contraction -- the numerics contract shared with the parity oracle.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-Wno-unused-value"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm to build libcaenv.so)")
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(s) > t for s in SOURCES)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library if it is missing or older than its sources; returns its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH, SOURCES[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,568 @@
+// ca_env.hip -- host side of libcaenv.so: the C ABI declared in include/ca_env.h.
+// Owns the device buffers (struct-of-arrays, fp32/int32), the obstacle table and the launch
+// geometry; every entry point enqueues work on the handle's stream.  No CPU fallback exists.
+#include "../../include/ca_env.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ca_kernels.h"
+
+using namespace ca;
+
+struct ca_env {
+    ca_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // [A*N] fp32
+    float *pos_x = nullptr, *pos_y = nullptr, *vel_x = nullptr, *vel_y = nullptr, *pref_x = nullptr,
+          *pref_y = nullptr, *goal_x = nullptr, *goal_y = nullptr, *goal2_x = nullptr, *goal2_y = nullptr,
+          *reward = nullptr;
+    int *agent_done = nullptr, *arrive_step = nullptr, *regoal_count = nullptr, *nb_count = nullptr,
+        *nb_idx = nullptr, *obst_count = nullptr, *obst_idx = nullptr;
+    int *step_count = nullptr, *arena_done = nullptr, *episode = nullptr;
+    unsigned long long* arena_stats = nullptr;
+    float* obs = nullptr;
+    bool obs_external = false;
+    float *tmp_x = nullptr, *tmp_y = nullptr;  // staging for explicit reset positions / host actions
+    ObstDev* d_obst = nullptr;
+    std::vector<ObstDev> h_obst;
+    int P = 1, logP = 0, BS = 64, grid = 1, K = 0, S = 1;
+    size_t lds = 0;
+    uint64_t steps_done = 0;  // env steps executed (agent_steps = steps_done * A * N)
+    float rays[32], oct[32];
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(ca_env* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+#define HIPCHK(e, call)                                                                         \
+    do {                                                                                        \
+        hipError_t _r = (call);                                                                 \
+        if (_r != hipSuccess) return fail(e, CA_EHIP, "%s failed: %s", #call, hipGetErrorString(_r)); \
+    } while (0)
+
+static size_t AN(const ca_env* e) { return (size_t)e->cfg.n_arenas * e->cfg.n_agents; }
+
+struct FieldInfo {
+    void* ptr;
+    size_t bytes;
+    bool writable;
+};
+static FieldInfo field_info(ca_env* e, int f) {
+    const size_t an = AN(e), A = e->cfg.n_arenas;
+    switch (f) {
+        case CA_FLD_POS_X: return {e->pos_x, an * 4, true};
+        case CA_FLD_POS_Y: return {e->pos_y, an * 4, true};
+        case CA_FLD_VEL_X: return {e->vel_x, an * 4, true};
+        case CA_FLD_VEL_Y: return {e->vel_y, an * 4, true};
+        case CA_FLD_PREF_X: return {e->pref_x, an * 4, true};
+        case CA_FLD_PREF_Y: return {e->pref_y, an * 4, true};
+        case CA_FLD_GOAL_X: return {e->goal_x, an * 4, true};
+        case CA_FLD_GOAL_Y: return {e->goal_y, an * 4, true};
+        case CA_FLD_GOAL2_X: return {e->goal2_x, an * 4, true};
+        case CA_FLD_GOAL2_Y: return {e->goal2_y, an * 4, true};
+        case CA_FLD_REWARD: return {e->reward, an * 4, false};
+        case CA_FLD_AGENT_DONE: return {e->agent_done, an * 4, true};
+        case CA_FLD_ARRIVE_STEP: return {e->arrive_step, an * 4, true};
+        case CA_FLD_NB_COUNT: return {e->nb_count, an * 4, true};
+        case CA_FLD_NB_IDX: return {e->nb_idx, an * 4 * (size_t)(e->K > 0 ? e->K : 1), true};
+        case CA_FLD_OBST_COUNT: return {e->obst_count, an * 4, true};
+        case CA_FLD_OBST_IDX: return {e->obst_idx, an * 4 * (size_t)e->S, true};
+        case CA_FLD_OBS: return {e->obs, an * CA_OBS_DIM * 4, false};
+        case CA_FLD_STEP_COUNT: return {e->step_count, A * 4, true};
+        case CA_FLD_ARENA_DONE: return {e->arena_done, A * 4, true};
+        case CA_FLD_EPISODE: return {e->episode, A * 4, true};
+        case CA_FLD_REGOAL_COUNT: return {e->regoal_count, an * 4, true};
+        default: return {nullptr, 0, false};
+    }
+}
+
+static void host_tables(ca_env* e) {
+    // env.py:321-332 ray end points; env.py:335-350 octagon chords (fp64 like the reference's
+    // Python floats, then rounded once to fp32)
+    const double nd = (double)e->cfg.neighbor_dist, r = (double)e->cfg.radius;
+    for (int i = 0; i < 16; ++i) {
+        const double th = i * (2.0 * M_PI / 16);
+        e->rays[2 * i] = (float)(nd * std::cos(th));
+        e->rays[2 * i + 1] = (float)(-nd * std::sin(th));
+    }
+    double first[2] = {r * std::cos(0.0), -r * std::sin(0.0)}, cur[2] = {first[0], first[1]};
+    int k = 0;
+    for (int i = 1; i < 8; ++i, ++k) {
+        const double th = i * (2.0 * M_PI / 8);
+        const double nx = r * std::cos(th), ny = -r * std::sin(th);
+        e->oct[4 * k] = (float)cur[0]; e->oct[4 * k + 1] = (float)cur[1];
+        e->oct[4 * k + 2] = (float)nx; e->oct[4 * k + 3] = (float)ny;
+        cur[0] = nx; cur[1] = ny;
+    }
+    e->oct[4 * k] = (float)cur[0]; e->oct[4 * k + 1] = (float)cur[1];
+    e->oct[4 * k + 2] = (float)first[0]; e->oct[4 * k + 3] = (float)first[1];
+}
+
+static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t flags) {
+    const ca_config& c = e->cfg;
+    a.pos_x = e->pos_x; a.pos_y = e->pos_y; a.vel_x = e->vel_x; a.vel_y = e->vel_y;
+    a.pref_x = e->pref_x; a.pref_y = e->pref_y; a.goal_x = e->goal_x; a.goal_y = e->goal_y;
+    a.goal2_x = e->goal2_x; a.goal2_y = e->goal2_y; a.reward = e->reward;
+    a.agent_done = e->agent_done; a.arrive_step = e->arrive_step; a.regoal_count = e->regoal_count;
+    a.nb_count = e->nb_count; a.nb_idx = e->nb_idx; a.obst_count = e->obst_count; a.obst_idx = e->obst_idx;
+    a.step_count = e->step_count; a.arena_done = e->arena_done; a.episode = e->episode;
+    a.arena_stats = e->arena_stats; a.obst = e->d_obst; a.actions = actions;
+    a.reset_px = nullptr; a.reset_py = nullptr;
+    a.reward_scale = c.reward_scale; a.seed = c.seed; a.arena_offset = c.arena_offset;
+    a.n_obst = (int)e->h_obst.size(); a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
+    a.K = e->K; a.S = e->S; a.flags = flags;
+    a.time_step = c.time_step; a.neighbor_dist = c.neighbor_dist; a.time_horizon = c.time_horizon;
+    a.time_horizon_obst = c.time_horizon_obst; a.radius = c.radius; a.max_speed = c.max_speed;
+    a.max_step = c.max_step; a.done_mode = c.done_mode; a.done_x_thresh = c.done_x_thresh;
+    a.spawn_x0 = c.spawn_x0; a.spawn_x1 = c.spawn_x1; a.spawn_y0 = c.spawn_y0; a.spawn_y1 = c.spawn_y1;
+    a.goal_x0 = c.goal_x0; a.goal_x1 = c.goal_x1; a.goal_y0 = c.goal_y0; a.goal_y1 = c.goal_y1;
+}
+
+template <int KMAX>
+static hipError_t launch_step_k(ca_env* e, const StepArgs& a) {
+    const dim3 grid(e->grid), block(e->BS);
+    switch (e->BS) {
+        case 64: hipLaunchKernelGGL((step_kernel<KMAX, 64>), grid, block, e->lds, e->stream, a); break;
+        case 128: hipLaunchKernelGGL((step_kernel<KMAX, 128>), grid, block, e->lds, e->stream, a); break;
+        case 256: hipLaunchKernelGGL((step_kernel<KMAX, 256>), grid, block, e->lds, e->stream, a); break;
+        case 512: hipLaunchKernelGGL((step_kernel<KMAX, 512>), grid, block, e->lds, e->stream, a); break;
+        default: hipLaunchKernelGGL((step_kernel<KMAX, 1024>), grid, block, e->lds, e->stream, a); break;
+    }
+    return hipGetLastError();
+}
+static hipError_t launch_step(ca_env* e, const StepArgs& a) {
+    if (e->K <= 5) return launch_step_k<5>(e, a);
+    if (e->K <= 10) return launch_step_k<10>(e, a);
+    return launch_step_k<16>(e, a);
+}
+
+template <int KMAX, int BS>
+static hipError_t set_lds_attr(size_t lds) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KMAX, BS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+template <int KMAX>
+static hipError_t set_lds_attr_k(int BS, size_t lds) {
+    switch (BS) {
+        case 64: return set_lds_attr<KMAX, 64>(lds);
+        case 128: return set_lds_attr<KMAX, 128>(lds);
+        case 256: return set_lds_attr<KMAX, 256>(lds);
+        case 512: return set_lds_attr<KMAX, 512>(lds);
+        default: return set_lds_attr<KMAX, 1024>(lds);
+    }
+}
+
+static hipError_t launch_obs(ca_env* e) {
+    ObsArgs o;
+    o.pos_x = e->pos_x; o.pos_y = e->pos_y; o.vel_x = e->vel_x; o.vel_y = e->vel_y;
+    o.goal_x = e->goal_x; o.goal_y = e->goal_y; o.nb_count = e->nb_count; o.nb_idx = e->nb_idx;
+    o.obst_count = e->obst_count; o.obst_idx = e->obst_idx; o.obst = e->d_obst; o.obs = e->obs;
+    o.A = e->cfg.n_arenas; o.N = e->cfg.n_agents; o.K = e->K > 0 ? e->K : 1; o.S = e->S;
+    if (e->K == 0) o.K = 1;  // nb_idx is allocated with one column; counts are all zero
+    memcpy(o.rays, e->rays, sizeof o.rays);
+    memcpy(o.oct, e->oct, sizeof o.oct);
+    const size_t total = AN(e);
+    const dim3 grid((unsigned)((total + OBS_APB - 1) / OBS_APB)), block(OBS_BS);
+    hipLaunchKernelGGL(obs_kernel, grid, block, obs_lds_bytes(o.K, o.S), e->stream, o);
+    return hipGetLastError();
+}
+
+template <class T>
+static hipError_t dalloc(T** p, size_t n) {
+    hipError_t r = hipMalloc((void**)p, n * sizeof(T));
+    if (r != hipSuccess) return r;
+    return hipMemset(*p, 0, n * sizeof(T));
+}
+
+extern "C" {
+
+const char* ca_last_error(const ca_env* env) { return env ? env->err.c_str() : g_create_err.c_str(); }
+
+int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
+    if (!cfg || !out) return fail(nullptr, CA_EINVAL, "ca_create: null argument");
+    *out = nullptr;
+    if (cfg->n_arenas <= 0 || cfg->n_agents <= 0 || cfg->n_agents > CA_MAX_AGENTS)
+        return fail(nullptr, CA_ERANGE, "ca_create: n_arenas=%d n_agents=%d out of range (agents 1..%d)",
+                    cfg->n_arenas, cfg->n_agents, CA_MAX_AGENTS);
+    if (cfg->max_neighbors < 0 || cfg->max_neighbors > CA_MAX_NEIGHBORS)
+        return fail(nullptr, CA_ERANGE, "ca_create: max_neighbors=%d out of range 0..%d", cfg->max_neighbors,
+                    CA_MAX_NEIGHBORS);
+    if (cfg->max_obst_neighbors < 1 || cfg->max_obst_neighbors > CA_MAX_OBST_NEIGHBORS)
+        return fail(nullptr, CA_ERANGE, "ca_create: max_obst_neighbors=%d out of range 1..%d",
+                    cfg->max_obst_neighbors, CA_MAX_OBST_NEIGHBORS);
+    if (cfg->done_mode < 0 || cfg->done_mode > 2) return fail(nullptr, CA_EINVAL, "ca_create: bad done_mode");
+    if ((size_t)cfg->n_arenas * cfg->n_agents > (size_t)1 << 30)
+        return fail(nullptr, CA_ERANGE, "ca_create: more than 2^30 agents on one handle");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, CA_ENODEV, "ca_create: no HIP device (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(nullptr, CA_ENODEV, "ca_create: device %d of %d", device, ndev);
+    ca_env* e = new ca_env();
+    e->cfg = *cfg;
+    e->device = device;
+    hipError_t r = hipSetDevice(device);
+    if (r == hipSuccess) {
+        if (stream) e->stream = (hipStream_t)stream;
+        else { r = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking); e->own_stream = true; }
+    }
+    // launch geometry: P lanes per arena (power of two >= N), one or more whole arenas per block
+    int P = 1, logP = 0;
+    while (P < cfg->n_agents) { P <<= 1; ++logP; }
+    e->P = P; e->logP = logP;
+    e->BS = P > 64 ? P : 64;
+    const int apb = e->BS / P;
+    e->grid = (cfg->n_arenas + apb - 1) / apb;
+    e->K = cfg->max_neighbors;
+    e->S = cfg->max_obst_neighbors;
+    e->lds = step_lds_bytes(e->BS, e->K, e->S);
+    host_tables(e);
+    const size_t an = AN(e), A = cfg->n_arenas;
+    float** f32s[] = {&e->pos_x, &e->pos_y, &e->vel_x, &e->vel_y, &e->pref_x, &e->pref_y, &e->goal_x,
+                      &e->goal_y, &e->goal2_x, &e->goal2_y, &e->reward, &e->tmp_x, &e->tmp_y};
+    for (auto p : f32s) if (r == hipSuccess) r = dalloc(p, an);
+    int** i32s[] = {&e->agent_done, &e->arrive_step, &e->regoal_count, &e->nb_count, &e->obst_count};
+    for (auto p : i32s) if (r == hipSuccess) r = dalloc(p, an);
+    if (r == hipSuccess) r = dalloc(&e->nb_idx, an * (size_t)(e->K > 0 ? e->K : 1));
+    if (r == hipSuccess) r = dalloc(&e->obst_idx, an * (size_t)e->S);
+    if (r == hipSuccess) r = dalloc(&e->step_count, A);
+    if (r == hipSuccess) r = dalloc(&e->arena_done, A);
+    if (r == hipSuccess) r = dalloc(&e->episode, A);
+    if (r == hipSuccess) r = dalloc(&e->arena_stats, A * ST_STRIDE);
+    if (r == hipSuccess) r = dalloc(&e->obs, an * CA_OBS_DIM);
+    if (r == hipSuccess) r = dalloc(&e->d_obst, (size_t)1);
+    if (r == hipSuccess && e->lds > 48 * 1024) {
+        if (e->K <= 5) r = set_lds_attr_k<5>(e->BS, e->lds);
+        else if (e->K <= 10) r = set_lds_attr_k<10>(e->BS, e->lds);
+        else r = set_lds_attr_k<16>(e->BS, e->lds);
+    }
+    if (r == hipSuccess && obs_lds_bytes(e->K > 0 ? e->K : 1, e->S) > 48 * 1024)
+        r = hipFuncSetAttribute(reinterpret_cast<const void*>(&obs_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)obs_lds_bytes(e->K > 0 ? e->K : 1, e->S));
+    if (r != hipSuccess) {
+        fail(nullptr, CA_EHIP, "ca_create: %s", hipGetErrorString(r));
+        ca_destroy(e);
+        return CA_EHIP;
+    }
+    if (e->lds > 160 * 1024) {
+        fail(nullptr, CA_ERANGE, "ca_create: step kernel needs %zu B of LDS (> 160 KiB): lower n_agents, "
+             "max_neighbors or max_obst_neighbors", e->lds);
+        ca_destroy(e);
+        return CA_ERANGE;
+    }
+    *out = e;
+    return CA_OK;
+}
+
+int ca_destroy(ca_env* e) {
+    if (!e) return CA_OK;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    void* bufs[] = {e->pos_x, e->pos_y, e->vel_x, e->vel_y, e->pref_x, e->pref_y, e->goal_x, e->goal_y,
+                    e->goal2_x, e->goal2_y, e->reward, e->tmp_x, e->tmp_y, e->agent_done, e->arrive_step,
+                    e->regoal_count, e->nb_count, e->nb_idx, e->obst_count, e->obst_idx, e->step_count,
+                    e->arena_done, e->episode, e->arena_stats, e->d_obst};
+    for (void* b : bufs) if (b) hipFree(b);
+    if (e->obs && !e->obs_external) hipFree(e->obs);
+    if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return CA_OK;
+}
+
+int ca_set_obstacles(ca_env* e, const float* verts_xy, const int32_t* poly_sizes, int32_t n_poly) {
+    if (!e || n_poly < 0 || (n_poly > 0 && (!verts_xy || !poly_sizes))) return fail(e, CA_EINVAL, "ca_set_obstacles: bad argument");
+    std::vector<ObstDev> tab;
+    size_t off = 0;
+    for (int pi = 0; pi < n_poly; ++pi) {
+        const int n = poly_sizes[pi];
+        if (n < 2) return fail(e, CA_EINVAL, "ca_set_obstacles: polygon %d has %d vertices (need >= 2)", pi, n);
+        const int base = (int)tab.size();
+        for (int i = 0; i < n; ++i) {  // SURVEY App. A.2 "Obstacle vertex attributes at addObstacle"
+            const int in = (i == n - 1) ? 0 : i + 1, ip = (i == 0) ? n - 1 : i - 1;
+            const V2 pt = mk(verts_xy[2 * (off + i)], verts_xy[2 * (off + i) + 1]);
+            const V2 pn = mk(verts_xy[2 * (off + in)], verts_xy[2 * (off + in) + 1]);
+            const V2 pp = mk(verts_xy[2 * (off + ip)], verts_xy[2 * (off + ip) + 1]);
+            const V2 u = normalize(pn - pt);
+            ObstDev o;
+            o.px = pt.x; o.py = pt.y; o.ux = u.x; o.uy = u.y;
+            o.next = base + in; o.prev = base + ip;
+            o.convex = (n == 2) ? 1 : (leftOf(pp, pt, pn) >= 0.0f ? 1 : 0);
+            o.pad = 0;
+            tab.push_back(o);
+        }
+        off += n;
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->d_obst) HIPCHK(e, hipFree(e->d_obst));
+    e->d_obst = nullptr;
+    HIPCHK(e, hipMalloc((void**)&e->d_obst, (tab.size() + 1) * sizeof(ObstDev)));
+    if (!tab.empty())
+        HIPCHK(e, hipMemcpy(e->d_obst, tab.data(), tab.size() * sizeof(ObstDev), hipMemcpyHostToDevice));
+    e->h_obst.swap(tab);
+    return CA_OK;
+}
+
+int ca_init_scenario(ca_env* e, int32_t scenario) {
+    if (!e) return CA_EINVAL;
+    if (scenario < 0 || scenario > 2) return fail(e, CA_EINVAL, "ca_init_scenario: unknown scenario %d", scenario);
+    const ca_config& c = e->cfg;
+    const int A = c.n_arenas, N = c.n_agents;
+    const size_t an = AN(e);
+    std::vector<float> px(an), py(an), vx(an), vy(an), gx(an), gy(an), g2x(an), g2y(an), fx(an), fy(an);
+    const double r = (double)c.radius;
+    for (int a = 0; a < A; ++a) {
+        const int64_t g = c.arena_offset + a;
+        double theta = 0.0;
+        for (int i = 0; i < N; ++i) {
+            const size_t q = (size_t)a * N + i;
+            double u0, u1, s, cs;
+            rng2(c.seed, g, i, RNG_HEADING, 0, &u0, &u1);
+            sincos64(uniform64(0.0, 2.0 * M_PI, u0), &s, &cs);  // env.py:89-90 / ALAN:276-277
+            vx[q] = (float)cs; vy[q] = (float)s;
+            if (scenario == CA_SCN_CROWD) {  // ALAN:270-283
+                const double E = std::sqrt(2.0 * r * N) * 2.0;
+                rng2(c.seed, g, i, RNG_POS, 0, &u0, &u1);
+                px[q] = (float)uniform64(0.0, E, u0); py[q] = (float)uniform64(0.0, E, u1);
+                rng2(c.seed, g, i, RNG_GOAL, 0, &u0, &u1);
+                gx[q] = (float)uniform64(0.0, E, u0); gy[q] = (float)uniform64(0.0, E, u1);
+                g2x[q] = gx[q]; g2y[q] = gy[q];
+            } else if (scenario == CA_SCN_CIRCLE) {  // ALAN:297-322
+                const double R = (r * 3 * N) / (2.0 * M_PI);
+                const double E = 2.0 * R + 4.0 * r;
+                px[q] = (float)(E / 2 + R * std::cos(theta)); py[q] = (float)(E / 2 + R * std::sin(theta));
+                gx[q] = (float)(E / 2 + R * std::cos(theta + M_PI));
+                gy[q] = (float)(E / 2 + R * std::sin(theta + M_PI));
+                g2x[q] = gx[q]; g2y[q] = gy[q];
+                theta += (2.0 * M_PI) / N;
+            } else {  // env.py:86-95, 361
+                const double E = 10.0;
+                rng2(c.seed, g, i, RNG_POS, 0, &u0, &u1);
+                px[q] = (float)uniform64(E * 0.5, E, u0); py[q] = (float)uniform64(0.0, E, u1);
+                gx[q] = 1.0f; gy[q] = 5.0f; g2x[q] = -10.0f; g2y[q] = 5.0f;
+            }
+            double dx, dy;  // env.py:97 update_pref_vel
+            pref_dir64(px[q], py[q], gx[q], gy[q], &dx, &dy);
+            fx[q] = (float)dx; fy[q] = (float)dy;
+        }
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    struct { float* d; std::vector<float>* h; } up[] = {{e->pos_x, &px}, {e->pos_y, &py}, {e->vel_x, &vx},
+        {e->vel_y, &vy}, {e->goal_x, &gx}, {e->goal_y, &gy}, {e->goal2_x, &g2x}, {e->goal2_y, &g2y},
+        {e->pref_x, &fx}, {e->pref_y, &fy}};
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (auto& u : up) HIPCHK(e, hipMemcpy(u.d, u.h->data(), an * 4, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemset(e->agent_done, 0, an * 4));
+    HIPCHK(e, hipMemset(e->arrive_step, 0xff, an * 4));
+    HIPCHK(e, hipMemset(e->regoal_count, 0, an * 4));
+    HIPCHK(e, hipMemset(e->nb_count, 0, an * 4));
+    HIPCHK(e, hipMemset(e->obst_count, 0, an * 4));
+    HIPCHK(e, hipMemset(e->step_count, 0, (size_t)A * 4));
+    HIPCHK(e, hipMemset(e->arena_done, 0, (size_t)A * 4));
+    HIPCHK(e, hipMemset(e->episode, 0, (size_t)A * 4));
+    HIPCHK(e, hipMemset(e->obs, 0, an * CA_OBS_DIM * 4));
+    return CA_OK;
+}
+
+int ca_set(ca_env* e, int32_t field, const void* src, size_t bytes, int32_t src_is_device) {
+    if (!e || !src) return fail(e, CA_EINVAL, "ca_set: null argument");
+    const FieldInfo fi = field_info(e, field);
+    if (!fi.ptr) return fail(e, CA_EINVAL, "ca_set: unknown field %d", field);
+    if (!fi.writable) return fail(e, CA_EINVAL, "ca_set: field %d is read-only", field);
+    if (bytes != fi.bytes) return fail(e, CA_ESIZE, "ca_set: field %d holds %zu bytes, got %zu", field, fi.bytes, bytes);
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemcpyAsync(fi.ptr, src, bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    if (!src_is_device) HIPCHK(e, hipStreamSynchronize(e->stream));
+    return CA_OK;
+}
+
+int ca_get(ca_env* e, int32_t field, void* dst, size_t bytes, int32_t dst_is_device) {
+    if (!e || !dst) return fail(e, CA_EINVAL, "ca_get: null argument");
+    const FieldInfo fi = field_info(e, field);
+    if (!fi.ptr) return fail(e, CA_EINVAL, "ca_get: unknown field %d", field);
+    if (bytes != fi.bytes) return fail(e, CA_ESIZE, "ca_get: field %d holds %zu bytes, got %zu", field, fi.bytes, bytes);
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemcpyAsync(dst, fi.ptr, bytes, dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
+    if (!dst_is_device) HIPCHK(e, hipStreamSynchronize(e->stream));
+    return CA_OK;
+}
+
+int ca_field_ptr(ca_env* e, int32_t field, void** dev_ptr, size_t* bytes) {
+    if (!e || !dev_ptr) return fail(e, CA_EINVAL, "ca_field_ptr: null argument");
+    const FieldInfo fi = field_info(e, field);
+    if (!fi.ptr) return fail(e, CA_EINVAL, "ca_field_ptr: unknown field %d", field);
+    *dev_ptr = fi.ptr;
+    if (bytes) *bytes = fi.bytes;
+    return CA_OK;
+}
+
+int ca_bind_obs(ca_env* e, void* dev_ptr, size_t bytes) {
+    if (!e || !dev_ptr) return fail(e, CA_EINVAL, "ca_bind_obs: null argument");
+    if (bytes != AN(e) * CA_OBS_DIM * 4)
+        return fail(e, CA_ESIZE, "ca_bind_obs: need %zu bytes, got %zu", AN(e) * CA_OBS_DIM * 4, bytes);
+    if (((uintptr_t)dev_ptr & 15) != 0) return fail(e, CA_EINVAL, "ca_bind_obs: buffer must be 16-byte aligned");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->obs && !e->obs_external) HIPCHK(e, hipFree(e->obs));
+    e->obs = (float*)dev_ptr;
+    e->obs_external = true;
+    return CA_OK;
+}
+
+int ca_reset(ca_env* e, const float* pos_x, const float* pos_y, int32_t pos_is_device, uint32_t flags) {
+    if (!e) return CA_EINVAL;
+    if ((pos_x == nullptr) != (pos_y == nullptr)) return fail(e, CA_EINVAL, "ca_reset: pos_x and pos_y go together");
+    HIPCHK(e, hipSetDevice(e->device));
+    StepArgs a;
+    fill_args(e, a, nullptr, flags);
+    if (pos_x) {
+        if (pos_is_device) { a.reset_px = pos_x; a.reset_py = pos_y; }
+        else {
+            HIPCHK(e, hipMemcpyAsync(e->tmp_x, pos_x, AN(e) * 4, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(e, hipMemcpyAsync(e->tmp_y, pos_y, AN(e) * 4, hipMemcpyHostToDevice, e->stream));
+            HIPCHK(e, hipStreamSynchronize(e->stream));  // the caller's host buffers may go away
+            a.reset_px = e->tmp_x; a.reset_py = e->tmp_y;
+        }
+    }
+    const unsigned an = (unsigned)AN(e);
+    hipLaunchKernelGGL(reset_kernel, dim3((an + 255) / 256), dim3(256), 0, e->stream, a);
+    HIPCHK(e, hipGetLastError());
+    hipLaunchKernelGGL(reset_arena_kernel, dim3((e->cfg.n_arenas + 255) / 256), dim3(256), 0, e->stream, a);
+    HIPCHK(e, hipGetLastError());
+    if (flags & CA_F_OBS) HIPCHK(e, launch_obs(e));
+    return CA_OK;
+}
+
+static int do_step(ca_env* e, const float* actions, uint32_t flags) {
+    StepArgs a;
+    fill_args(e, a, actions, flags);
+    HIPCHK(e, launch_step(e, a));
+    if (flags & CA_F_OBS) HIPCHK(e, launch_obs(e));
+    e->steps_done += 1;
+    return CA_OK;
+}
+
+int ca_step(ca_env* e, const float* actions, uint32_t flags) {
+    if (!e) return CA_EINVAL;
+    if (!actions) return fail(e, CA_EINVAL, "ca_step: actions is null (use ca_orca_step for the ORCA-only step)");
+    if (flags & CA_F_NODONE) return fail(e, CA_EINVAL, "ca_step: CA_F_NODONE applies to ca_orca_step only");
+    HIPCHK(e, hipSetDevice(e->device));
+    return do_step(e, actions, flags);
+}
+
+int ca_step_host(ca_env* e, const float* actions_host, uint32_t flags) {
+    if (!e) return CA_EINVAL;
+    if (!actions_host) return fail(e, CA_EINVAL, "ca_step_host: actions is null");
+    if (flags & CA_F_NODONE) return fail(e, CA_EINVAL, "ca_step_host: CA_F_NODONE applies to ca_orca_step only");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemcpyAsync(e->tmp_x, actions_host, AN(e) * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));  // the caller's buffer may be reused right away
+    return do_step(e, e->tmp_x, flags);
+}
+
+int ca_orca_step(ca_env* e, uint32_t flags) {
+    if (!e) return CA_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    return do_step(e, nullptr, flags);
+}
+
+int ca_observe(ca_env* e) {
+    if (!e) return CA_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, launch_obs(e));
+    return CA_OK;
+}
+
+int ca_rollout(ca_env* e, int32_t steps, uint32_t flags) {
+    if (!e || steps < 0) return fail(e, CA_EINVAL, "ca_rollout: bad argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    for (int s = 0; s < steps; ++s) {
+        const int rc = do_step(e, nullptr, flags);
+        if (rc) return rc;
+    }
+    return CA_OK;
+}
+
+int ca_sync(ca_env* e) {
+    if (!e) return CA_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return CA_OK;
+}
+
+int ca_get_stats(ca_env* e, ca_stats* out) {
+    if (!e || !out) return fail(e, CA_EINVAL, "ca_get_stats: null argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t A = e->cfg.n_arenas;
+    std::vector<unsigned long long> h(A * ST_STRIDE);
+    HIPCHK(e, hipMemcpyAsync(h.data(), e->arena_stats, h.size() * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    ca_stats s;
+    memset(&s, 0, sizeof s);
+    for (size_t a = 0; a < A; ++a) {
+        const unsigned long long* r = &h[a * ST_STRIDE];
+        s.episodes += r[ST_EPISODES]; s.collisions += r[ST_COLL]; s.obst_collisions += r[ST_OBST_COLL];
+        s.goals_reached += r[ST_GOALS]; s.obst_overflow += r[ST_OVERFLOW];
+        double d;
+        memcpy(&d, &r[ST_SUMREW], 8);
+        s.sum_reward += d;
+    }
+    s.agent_steps = e->steps_done * (uint64_t)AN(e);
+    *out = s;
+    return CA_OK;
+}
+
+int ca_reset_stats(ca_env* e) {
+    if (!e) return CA_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemsetAsync(e->arena_stats, 0, (size_t)e->cfg.n_arenas * ST_STRIDE * 8, e->stream));
+    e->steps_done = 0;
+    return CA_OK;
+}
+
+int ca_debug_math(ca_env* e, int32_t op, const void* in, void* out, int32_t n) {
+    if (!e || !in || !out || n <= 0 || op < 0 || op > 4) return fail(e, CA_EINVAL, "ca_debug_math: bad argument");
+    static const size_t in_b[] = {4, 8, 8, 16, 16}, out_b[] = {4, 4, 16, 16, 16};
+    HIPCHK(e, hipSetDevice(e->device));
+    void *di = nullptr, *dout = nullptr;
+    HIPCHK(e, hipMalloc(&di, in_b[op] * n));
+    HIPCHK(e, hipMalloc(&dout, out_b[op] * n));
+    HIPCHK(e, hipMemcpy(di, in, in_b[op] * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, op, di, dout, n, e->cfg.seed);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(out, dout, out_b[op] * n, hipMemcpyDeviceToHost));
+    hipFree(di);
+    hipFree(dout);
+    return CA_OK;
+}
+
+int ca_launch_info(ca_env* e, int32_t* block, int32_t* grid, int32_t* lds_bytes, int32_t* obs_grid) {
+    if (!e) return CA_EINVAL;
+    if (block) *block = e->BS;
+    if (grid) *grid = e->grid;
+    if (lds_bytes) *lds_bytes = (int32_t)e->lds;
+    if (obs_grid) *obs_grid = (int32_t)((AN(e) + OBS_APB - 1) / OBS_APB);
+    return CA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,778 @@
+// ca_kernels.h -- HIP kernels of the batched collision-avoidance step for gfx950 (MI355X).
+//
+// Mapping: one LANE per agent, one workgroup per group of arenas (a
+// workgroup never splits an arena).  The arena's positions/velocities are staged once into LDS;
+// every agent then scans its arena from LDS (broadcast reads), keeps its K nearest neighbours in
+// registers, builds its ORCA half-planes into an LDS line table laid out [line][lane] (16 B per
+// lane, conflict-free) and solves the 2-D LP over that table.  Arenas are independent, so there
+// is no inter-workgroup traffic and no XCD affinity to exploit: the grid is simply arena-major.
+//
+// Numerics contract: fp32, no FMA contraction (-ffp-contract=off), IEEE sqrt and division, the
+// operation order of SURVEY.md Appendix A.  The CPU oracle (oracle/) obeys the same contract, so
+// trajectories agree bit for bit.
+#pragma once
+#include "ca_math.h"
+
+namespace ca {
+
+constexpr int SMAX = 8;       // CA_MAX_OBST_NEIGHBORS
+constexpr float EPS = 0.00001f;
+
+struct ObstDev {  // one obstacle vertex; the edge is (this, next)
+    float px, py, ux, uy;
+    int next, prev, convex, pad;
+};
+
+struct Line {
+    V2 point, dir;
+};
+
+struct StepArgs {
+    float *pos_x, *pos_y, *vel_x, *vel_y, *pref_x, *pref_y, *goal_x, *goal_y;
+    const float *goal2_x, *goal2_y;
+    float* reward;
+    int *agent_done, *arrive_step, *regoal_count;
+    int *nb_count, *nb_idx, *obst_count, *obst_idx;
+    int *step_count, *arena_done, *episode;
+    unsigned long long* arena_stats;  // [A][8]
+    const ObstDev* obst;
+    const float* actions;  // null: orca_step
+    const float* reset_px; // explicit reset positions (reset kernel only)
+    const float* reset_py;
+    double reward_scale;
+    uint64_t seed;
+    int64_t arena_offset;
+    int n_obst, A, N, P, logP, K, S;
+    uint32_t flags;
+    float time_step, neighbor_dist, time_horizon, time_horizon_obst, radius, max_speed;
+    int max_step, done_mode;
+    float done_x_thresh;
+    float spawn_x0, spawn_x1, spawn_y0, spawn_y1, goal_x0, goal_x1, goal_y0, goal_y1;
+};
+
+enum { ST_EPISODES = 0, ST_COLL = 1, ST_OBST_COLL = 2, ST_GOALS = 3, ST_OVERFLOW = 4, ST_SUMREW = 5, ST_STRIDE = 8 };
+
+// ---- line tables ---------------------------------------------------------------------------
+struct LdsLines {  // [line][lane] float4 = (point.x, point.y, dir.x, dir.y)
+    float4* base;  // already offset by the lane
+    int stride;    // lanes per workgroup
+    __device__ __forceinline__ Line get(int j) const {
+        const float4 v = base[j * stride];
+        Line l; l.point = mk(v.x, v.y); l.dir = mk(v.z, v.w);
+        return l;
+    }
+    __device__ __forceinline__ void put(int j, const Line& l) const {
+        base[j * stride] = make_float4(l.point.x, l.point.y, l.dir.x, l.dir.y);
+    }
+};
+struct PrivLines {
+    const Line* p;
+    __device__ __forceinline__ Line get(int j) const { return p[j]; }
+};
+
+// App. A.5 LP1
+template <class LS>
+__device__ __forceinline__ bool lp1(const LS& ls, int lineNo, float radius, V2 opt, bool dirOpt, V2& result) {
+    const Line L = ls.get(lineNo);
+    const float dp = dot(L.point, L.dir);
+    const float disc = sqr(dp) + sqr(radius) - absSq(L.point);
+    if (disc < 0.0f) return false;
+    const float sq = sqrtf(disc);
+    float tLeft = -dp - sq;
+    float tRight = -dp + sq;
+    for (int j = 0; j < lineNo; ++j) {
+        const Line M = ls.get(j);
+        const float den = det(L.dir, M.dir);
+        const float num = det(M.dir, L.point - M.point);
+        if (fabsf(den) <= EPS) {
+            if (num < 0.0f) return false;
+            continue;
+        }
+        const float t = num / den;
+        if (den >= 0.0f) tRight = (t < tRight) ? t : tRight;
+        else tLeft = (tLeft < t) ? t : tLeft;
+        if (tLeft > tRight) return false;
+    }
+    if (dirOpt) {
+        if (dot(opt, L.dir) > 0.0f) result = L.point + tRight * L.dir;
+        else result = L.point + tLeft * L.dir;
+    } else {
+        const float t = dot(L.dir, opt - L.point);
+        if (t < tLeft) result = L.point + tLeft * L.dir;
+        else if (t > tRight) result = L.point + tRight * L.dir;
+        else result = L.point + t * L.dir;
+    }
+    return true;
+}
+
+// App. A.5 LP2
+template <class LS>
+__device__ __forceinline__ int lp2(const LS& ls, int n, float radius, V2 opt, bool dirOpt, V2& result) {
+    if (dirOpt) result = opt * radius;
+    else if (absSq(opt) > sqr(radius)) result = normalize(opt) * radius;
+    else result = opt;
+    for (int i = 0; i < n; ++i) {
+        const Line L = ls.get(i);
+        if (det(L.dir, L.point - result) > 0.0f) {
+            const V2 tmp = result;
+            if (!lp1(ls, i, radius, opt, dirOpt, result)) {
+                result = tmp;
+                return i;
+            }
+        }
+    }
+    return n;
+}
+
+// App. A.5 LP3 (rare: only when LP2 is infeasible).  The projected lines live in private memory.
+template <int MAXL>
+__device__ __noinline__ void lp3(LdsLines ls, int n, int numObst, int begin, float radius, V2& result) {
+    Line proj[MAXL];
+    float distance = 0.0f;
+    for (int i = begin; i < n; ++i) {
+        const Line Li = ls.get(i);
+        if (det(Li.dir, Li.point - result) > distance) {
+            int m = 0;
+            for (int j = 0; j < numObst; ++j) proj[m++] = ls.get(j);
+            for (int j = numObst; j < i; ++j) {
+                const Line Lj = ls.get(j);
+                Line l;
+                const float d = det(Li.dir, Lj.dir);
+                if (fabsf(d) <= EPS) {
+                    if (dot(Li.dir, Lj.dir) > 0.0f) continue;
+                    l.point = 0.5f * (Li.point + Lj.point);
+                } else {
+                    l.point = Li.point + (det(Lj.dir, Li.point - Lj.point) / d) * Li.dir;
+                }
+                l.dir = normalize(Lj.dir - Li.dir);
+                proj[m++] = l;
+            }
+            const V2 tmp = result;
+            PrivLines pl; pl.p = proj;
+            if (lp2(pl, m, radius, mk(-Li.dir.y, Li.dir.x), true, result) < m) result = tmp;
+            distance = det(Li.dir, Li.point - result);
+        }
+    }
+}
+
+// App. A.4: the half-plane induced by one neighbouring agent (both agents have radius R)
+__device__ __forceinline__ Line agent_orca_line(V2 pos, V2 vel, V2 opos, V2 ovel, float R, float invT, float invDt) {
+    const V2 rp = opos - pos;
+    const V2 rv = vel - ovel;
+    const float distSq = absSq(rp);
+    const float cr = R + R;
+    const float crSq = sqr(cr);
+    Line line;
+    V2 u;
+    if (distSq > crSq) {
+        const V2 w = rv - invT * rp;
+        const float wLenSq = absSq(w);
+        const float dp1 = dot(w, rp);
+        if (dp1 < 0.0f && sqr(dp1) > crSq * wLenSq) {
+            const float wLen = sqrtf(wLenSq);
+            const V2 unitW = vdiv(w, wLen);
+            line.dir = mk(unitW.y, -unitW.x);
+            u = (cr * invT - wLen) * unitW;
+        } else {
+            const float leg = sqrtf(distSq - crSq);
+            if (det(rp, w) > 0.0f)
+                line.dir = vdiv(mk(rp.x * leg - rp.y * cr, rp.x * cr + rp.y * leg), distSq);
+            else
+                line.dir = -vdiv(mk(rp.x * leg + rp.y * cr, -rp.x * cr + rp.y * leg), distSq);
+            const float dp2 = dot(rv, line.dir);
+            u = dp2 * line.dir - rv;
+        }
+    } else {
+        const V2 w = rv - invDt * rp;
+        const float wLen = vabs(w);
+        const V2 unitW = vdiv(w, wLen);
+        line.dir = mk(unitW.y, -unitW.x);
+        u = (cr * invDt - wLen) * unitW;
+    }
+    line.point = vel + 0.5f * u;
+    return line;
+}
+
+__device__ __forceinline__ ObstDev load_obst(const ObstDev* __restrict__ t, int i) {
+    const int4* q = reinterpret_cast<const int4*>(t + i);
+    const int4 a = q[0], b = q[1];
+    ObstDev o;
+    o.px = __int_as_float(a.x); o.py = __int_as_float(a.y); o.ux = __int_as_float(a.z); o.uy = __int_as_float(a.w);
+    o.next = b.x; o.prev = b.y; o.convex = b.z; o.pad = 0;
+    return o;
+}
+
+// App. A.3: the half-plane induced by the obstacle edge starting at vertex i1.  Returns false
+// when the edge yields no line (already covered, non-convex vertex, foreign leg).
+__device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, int i1, V2 pos, V2 vel, float R,
+                                               float invTO, const LdsLines& ls, int nl, Line& line) {
+    ObstDev o1 = load_obst(tab, i1);
+    int i2 = o1.next;
+    ObstDev o2 = load_obst(tab, i2);
+    const V2 rp1 = mk(o1.px, o1.py) - pos;
+    const V2 rp2 = mk(o2.px, o2.py) - pos;
+    for (int j = 0; j < nl; ++j) {
+        const Line M = ls.get(j);
+        if (det(invTO * rp1 - M.point, M.dir) - invTO * R >= -EPS &&
+            det(invTO * rp2 - M.point, M.dir) - invTO * R >= -EPS)
+            return false;
+    }
+    const float distSq1 = absSq(rp1), distSq2 = absSq(rp2), radiusSq = sqr(R);
+    const V2 ov = mk(o2.px, o2.py) - mk(o1.px, o1.py);
+    const float s = dot(-rp1, ov) / absSq(ov);
+    const float distSqLine = absSq(-rp1 - s * ov);
+    if (s < 0.0f && distSq1 <= radiusSq) {
+        if (o1.convex) {
+            line.point = mk(0.0f, 0.0f);
+            line.dir = normalize(mk(-rp1.y, rp1.x));
+            return true;
+        }
+        return false;
+    } else if (s > 1.0f && distSq2 <= radiusSq) {
+        if (o2.convex && det(rp2, mk(o2.ux, o2.uy)) >= 0.0f) {
+            line.point = mk(0.0f, 0.0f);
+            line.dir = normalize(mk(-rp2.y, rp2.x));
+            return true;
+        }
+        return false;
+    } else if (s >= 0.0f && s < 1.0f && distSqLine <= radiusSq) {
+        line.point = mk(0.0f, 0.0f);
+        line.dir = -mk(o1.ux, o1.uy);
+        return true;
+    }
+    V2 leftLeg, rightLeg;
+    if (s < 0.0f && distSqLine <= radiusSq) {
+        if (!o1.convex) return false;
+        o2 = o1; i2 = i1;
+        const float leg1 = sqrtf(distSq1 - radiusSq);
+        leftLeg = vdiv(mk(rp1.x * leg1 - rp1.y * R, rp1.x * R + rp1.y * leg1), distSq1);
+        rightLeg = vdiv(mk(rp1.x * leg1 + rp1.y * R, -rp1.x * R + rp1.y * leg1), distSq1);
+    } else if (s > 1.0f && distSqLine <= radiusSq) {
+        if (!o2.convex) return false;
+        o1 = o2; i1 = i2;
+        const float leg2 = sqrtf(distSq2 - radiusSq);
+        leftLeg = vdiv(mk(rp2.x * leg2 - rp2.y * R, rp2.x * R + rp2.y * leg2), distSq2);
+        rightLeg = vdiv(mk(rp2.x * leg2 + rp2.y * R, -rp2.x * R + rp2.y * leg2), distSq2);
+    } else {
+        if (o1.convex) {
+            const float leg1 = sqrtf(distSq1 - radiusSq);
+            leftLeg = vdiv(mk(rp1.x * leg1 - rp1.y * R, rp1.x * R + rp1.y * leg1), distSq1);
+        } else {
+            leftLeg = -mk(o1.ux, o1.uy);
+        }
+        if (o2.convex) {
+            const float leg2 = sqrtf(distSq2 - radiusSq);
+            rightLeg = vdiv(mk(rp2.x * leg2 + rp2.y * R, -rp2.x * R + rp2.y * leg2), distSq2);
+        } else {
+            rightLeg = mk(o1.ux, o1.uy);
+        }
+    }
+    const ObstDev ln = load_obst(tab, o1.prev);
+    bool leftForeign = false, rightForeign = false;
+    if (o1.convex && det(leftLeg, -mk(ln.ux, ln.uy)) >= 0.0f) {
+        leftLeg = -mk(ln.ux, ln.uy);
+        leftForeign = true;
+    }
+    if (o2.convex && det(rightLeg, mk(o2.ux, o2.uy)) <= 0.0f) {
+        rightLeg = mk(o2.ux, o2.uy);
+        rightForeign = true;
+    }
+    const V2 leftCut = invTO * (mk(o1.px, o1.py) - pos);
+    const V2 rightCut = invTO * (mk(o2.px, o2.py) - pos);
+    const V2 cutVec = rightCut - leftCut;
+    const bool same = (i1 == i2);
+    const float t = same ? 0.5f : dot(vel - leftCut, cutVec) / absSq(cutVec);
+    const float tLeft = dot(vel - leftCut, leftLeg);
+    const float tRight = dot(vel - rightCut, rightLeg);
+    if ((t < 0.0f && tLeft < 0.0f) || (same && tLeft < 0.0f && tRight < 0.0f)) {
+        const V2 unitW = normalize(vel - leftCut);
+        line.dir = mk(unitW.y, -unitW.x);
+        line.point = leftCut + R * invTO * unitW;
+        return true;
+    } else if (t > 1.0f && tRight < 0.0f) {
+        const V2 unitW = normalize(vel - rightCut);
+        line.dir = mk(unitW.y, -unitW.x);
+        line.point = rightCut + R * invTO * unitW;
+        return true;
+    }
+    const float INF = __int_as_float(0x7f800000);
+    const float dCut = (t < 0.0f || t > 1.0f || same) ? INF : absSq(vel - (leftCut + t * cutVec));
+    const float dLeft = (tLeft < 0.0f) ? INF : absSq(vel - (leftCut + tLeft * leftLeg));
+    const float dRight = (tRight < 0.0f) ? INF : absSq(vel - (rightCut + tRight * rightLeg));
+    if (dCut <= dLeft && dCut <= dRight) {
+        line.dir = -mk(o1.ux, o1.uy);
+        line.point = leftCut + R * invTO * mk(-line.dir.y, line.dir.x);
+        return true;
+    } else if (dLeft <= dRight) {
+        if (leftForeign) return false;
+        line.dir = leftLeg;
+        line.point = leftCut + R * invTO * mk(-line.dir.y, line.dir.x);
+        return true;
+    }
+    if (rightForeign) return false;
+    line.dir = -rightLeg;
+    line.point = rightCut + R * invTO * mk(-line.dir.y, line.dir.x);
+    return true;
+}
+
+// sorted insertion into a register-resident list: keeps the `cap` smallest keys ascending; a new
+// key goes behind every key <= it (strict <), displaced entries move down, the last falls off
+template <int MAXN>
+__device__ __forceinline__ void sorted_insert(float (&d)[MAXN], int (&idx)[MAXN], int cap, float nd, int ni) {
+    bool ins = false;
+#pragma unroll
+    for (int k = 0; k < MAXN; ++k) {
+        const bool sw = (k < cap) && (ins || nd < d[k]);
+        const float td = d[k];
+        const int ti = idx[k];
+        d[k] = sw ? nd : td;
+        idx[k] = sw ? ni : ti;
+        nd = sw ? td : nd;
+        ni = sw ? ti : ni;
+        ins = sw;
+    }
+}
+template <int MAXN>
+__device__ __forceinline__ int pick(const int (&v)[MAXN], int k) {
+    int r = v[0];
+#pragma unroll
+    for (int j = 1; j < MAXN; ++j) r = (k == j) ? v[j] : r;
+    return r;
+}
+template <int MAXN>
+__device__ __forceinline__ float pickf(const float (&v)[MAXN], int k) {
+    float r = v[0];
+#pragma unroll
+    for (int j = 1; j < MAXN; ++j) r = (k == j) ? v[j] : r;
+    return r;
+}
+
+// LDS carve-up of the step kernel (bytes): lines | px py vx vy | misc ints
+__host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S) {
+    return (size_t)BS * ((size_t)(K + S) * 16 + 16 + 16);
+}
+
+// ============================================================================================
+// One environment step for every arena (SURVEY.md A5/A6 -> A10-A15 -> A16-A18 + A20).
+// actions != null : env.py:367-416 `step`;  actions == null : `orca_step` (env.py:447-450,
+// ALAN:631-636) followed by the done test of ALAN:118-121 unless CA_F_NODONE.
+// ============================================================================================
+template <int KMAX, int BS>
+__global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
+    extern __shared__ float4 smem4[];
+    const int tid = threadIdx.x;
+    const int P = p.P;
+    const int la = tid >> p.logP;
+    const int i = tid & (P - 1);
+    const int apb = BS >> p.logP;
+    const int a = blockIdx.x * apb + la;
+    const bool active = (a < p.A) && (i < p.N);
+    const int N = p.N, K = p.K, S = p.S;
+    const int q = active ? a * N + i : 0;
+    const int lbase = la << p.logP;
+
+    float4* s_lines = smem4;                                   // [(K+S)][BS]
+    float* s_px = reinterpret_cast<float*>(smem4 + (size_t)(K + S) * BS);
+    float* s_py = s_px + BS;
+    float* s_vx = s_py + BS;
+    float* s_vy = s_vx + BS;
+    int* s_misc = reinterpret_cast<int*>(s_vy + BS);            // [BS][4]
+    LdsLines ls; ls.base = s_lines + tid; ls.stride = BS;
+
+    // ---- load own state (coalesced SoA) ----
+    V2 pos = mk(0.0f, 0.0f), vel = mk(0.0f, 0.0f), pref = mk(0.0f, 0.0f);
+    float gx = 0.0f, gy = 0.0f;
+    int done = 1;
+    double pf_x = 1.0, pf_y = 0.0, rl_x = 1.0, rl_y = 0.0;
+    if (active) {
+        pos = mk(p.pos_x[q], p.pos_y[q]);
+        vel = mk(p.vel_x[q], p.vel_y[q]);
+        gx = p.goal_x[q]; gy = p.goal_y[q];
+        done = p.agent_done[q];
+        if (p.actions) {  // env.py:371-383
+            pref_dir64(pos.x, pos.y, gx, gy, &pf_x, &pf_y);
+            double sn, cs;
+            sincos64((double)p.actions[q], &sn, &cs);
+            rl_x = pf_x * cs - pf_y * sn;
+            rl_y = pf_x * sn + pf_y * cs;
+            pref = mk((float)rl_x, (float)rl_y);
+        } else {
+            pref = mk(p.pref_x[q], p.pref_y[q]);
+        }
+    }
+    s_px[tid] = pos.x; s_py[tid] = pos.y; s_vx[tid] = vel.x; s_vy[tid] = vel.y;
+    __syncthreads();
+
+    const float INF = __int_as_float(0x7f800000);
+    // ---- obstacle neighbours (App. A.2): brute force over the edge table ----
+    float od[SMAX]; int oi[SMAX];
+#pragma unroll
+    for (int k = 0; k < SMAX; ++k) { od[k] = INF; oi[k] = -1; }
+    int oin = 0;
+    {
+        const float rangeSq = sqr(p.time_horizon_obst * p.max_speed + p.radius);
+        for (int e = 0; e < p.n_obst; ++e) {
+            const ObstDev o1 = p.obst[e];
+            const ObstDev o2 = p.obst[o1.next];
+            const V2 a1 = mk(o1.px, o1.py), a2 = mk(o2.px, o2.py);
+            const float alol = leftOf(a1, a2, pos);
+            const float dsl = sqr(alol) / absSq(a2 - a1);
+            if (active && dsl < rangeSq && alol < 0.0f) {
+                const float dsq = distSqPointSegment(a1, a2, pos);
+                if (dsq < rangeSq) {
+                    ++oin;
+                    sorted_insert<SMAX>(od, oi, S, dsq, e);
+                }
+            }
+        }
+    }
+    const int ocnt = oin < S ? oin : S;
+
+    // ---- agent neighbours (App. A.2): K nearest within neighbor_dist, ties -> lower index ----
+    float nd[KMAX]; int ni[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { nd[k] = INF; ni[k] = -1; }
+    int ncnt = 0;
+    if (K > 0) {
+        float rangeSq = sqr(p.neighbor_dist);
+        for (int j = 0; j < N; ++j) {
+            const V2 o = mk(s_px[lbase + j], s_py[lbase + j]);
+            const float dsq = absSq(pos - o);
+            if (active && j != i && dsq < rangeSq) {
+                sorted_insert<KMAX>(nd, ni, K, dsq, j);
+                if (ncnt < K) ++ncnt;
+                if (ncnt == K) rangeSq = (K == KMAX) ? nd[KMAX - 1] : pickf<KMAX>(nd, K - 1);
+            }
+        }
+    }
+
+    // ---- ORCA lines -> LDS table ----
+    int nl = 0;
+    const float R = p.radius;
+    {
+        const float invTO = 1.0f / p.time_horizon_obst;
+        for (int s = 0; s < S; ++s) {
+            if (s < ocnt) {
+                Line line;
+                if (obst_orca_line(p.obst, pick<SMAX>(oi, s), pos, vel, R, invTO, ls, nl, line)) {
+                    ls.put(nl, line);
+                    ++nl;
+                }
+            }
+        }
+    }
+    const int numObstLines = nl;
+    {
+        const float invT = 1.0f / p.time_horizon;
+        const float invDt = 1.0f / p.time_step;
+        for (int k = 0; k < K; ++k) {
+            if (k < ncnt) {
+                const int j = lbase + pick<KMAX>(ni, k);
+                const Line line = agent_orca_line(pos, vel, mk(s_px[j], s_py[j]), mk(s_vx[j], s_vy[j]), R, invT, invDt);
+                ls.put(nl, line);
+                ++nl;
+            }
+        }
+    }
+
+    // ---- 2-D linear program (App. A.5) ----
+    V2 nv = mk(0.0f, 0.0f);
+    if (active) {
+        const int fail = lp2(ls, nl, p.max_speed, pref, false, nv);
+        if (fail < nl) lp3<KMAX + SMAX>(ls, nl, numObstLines, fail, p.max_speed, nv);
+        // ---- integrate (App. A.1) ----
+        vel = nv;
+        pos = pos + vel * p.time_step;
+    }
+
+    __syncthreads();  // every lane is done with the pre-step arena image
+    s_px[tid] = pos.x; s_py[tid] = pos.y;
+    s_misc[tid * 4 + 0] = 0; s_misc[tid * 4 + 1] = 0; s_misc[tid * 4 + 2] = 0; s_misc[tid * 4 + 3] = 0;
+    __syncthreads();
+    int* red = s_misc + la * 4;  // per-arena: [0] not-done agents, [1] pairs, [2] wall hits, [3] goals
+
+    if (active) {
+        if (oin > S) atomicAdd(reinterpret_cast<int*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_OVERFLOW]), 1);
+        if (p.flags & 2u) {  // CA_F_STATS
+            int pairs = 0;
+            const float crSq = sqr(R + R);
+            for (int j = i + 1; j < N; ++j)
+                if (absSq(pos - mk(s_px[lbase + j], s_py[lbase + j])) < crSq) ++pairs;
+            bool wall = false;
+            for (int e = 0; e < p.n_obst; ++e) {
+                const ObstDev o1 = p.obst[e];
+                const ObstDev o2 = p.obst[o1.next];
+                if (distSqPointSegment(mk(o1.px, o1.py), mk(o2.px, o2.py), pos) < sqr(R)) wall = true;
+            }
+            if (pairs) atomicAdd(&red[1], pairs);
+            if (wall) atomicAdd(&red[2], 1);
+        }
+    }
+
+    // ---- reward (env.py:389-400) or preferred velocity towards the goal (env.py:449) ----
+    float rew = 0.0f;
+    if (active) {
+        if (p.actions) {
+            const float scale = (float)p.reward_scale;
+            const float r_goal = vel.x * (float)pf_x + vel.y * (float)pf_y;
+            const float r_polite = vel.x * (float)rl_x + vel.y * (float)rl_y;
+            rew = scale * r_goal + (1.0f - scale) * r_polite;
+            p.reward[q] = rew;
+        } else {
+            double dx, dy;
+            pref_dir64(pos.x, pos.y, gx, gy, &dx, &dy);
+            pref = mk((float)dx, (float)dy);
+        }
+    }
+
+    // ---- step counter and done test (env.py:352-365, 404-410; ALAN:118-121, 547-566) ----
+    const bool nodone = (p.flags & 8u) != 0;  // CA_F_NODONE
+    int steps = active ? p.step_count[a] : 0;
+    if (!p.actions && !nodone) ++steps;
+    if (active && !nodone) {
+        bool hit = false;
+        if (p.done_mode == 0) {
+            hit = (done == 0) && (pos.x < p.done_x_thresh);
+        } else {
+            const double dx = (double)pos.x - (double)gx, dy = (double)pos.y - (double)gy;
+            const double lim = 2.0 * (double)p.radius;
+            hit = (dx * dx + dy * dy) < lim * lim;
+            if (p.done_mode == 1) hit = hit && (done == 0);
+        }
+        if (hit) {
+            if (p.done_mode == 2) {
+                const int rc = p.regoal_count[q];
+                double u0, u1;
+                rng2(p.seed, p.arena_offset + a, i, RNG_REGOAL, (uint32_t)rc, &u0, &u1);
+                gx = (float)uniform64((double)p.goal_x0, (double)p.goal_x1, u0);
+                gy = (float)uniform64((double)p.goal_y0, (double)p.goal_y1, u1);
+                p.regoal_count[q] = rc + 1;
+            } else {
+                done = 1;
+                p.arrive_step[q] = steps;
+                gx = p.goal2_x[q]; gy = p.goal2_y[q];
+                p.agent_done[q] = 1;
+            }
+            p.goal_x[q] = gx; p.goal_y[q] = gy;
+            atomicAdd(&red[3], 1);
+        }
+    }
+    if (p.actions) ++steps;
+    if (active && done == 0) atomicAdd(&red[0], 1);
+    __syncthreads();
+
+    bool all_done = false;
+    if (active) {
+        all_done = !nodone && (red[0] == 0);
+        if (p.max_step > 0 && steps >= p.max_step) all_done = true;
+    }
+    const bool do_reset = all_done && (p.flags & 4u);  // CA_F_AUTORESET
+    int epi = 0;
+    if (do_reset) {  // env.py:461-488 for this arena
+        epi = p.episode[a];
+        double u0, u1;
+        rng2(p.seed, p.arena_offset + a, i, RNG_RESET, (uint32_t)epi, &u0, &u1);
+        pos = mk((float)uniform64((double)p.spawn_x0, (double)p.spawn_x1, u0),
+                 (float)uniform64((double)p.spawn_y0, (double)p.spawn_y1, u1));
+        done = 0;
+        p.agent_done[q] = 0;
+        double dx, dy;
+        pref_dir64(pos.x, pos.y, gx, gy, &dx, &dy);
+        pref = mk((float)dx, (float)dy);
+    }
+    // sum of rewards: fixed-shape tree inside the wave, then per-arena in lane order
+    if (p.actions && (p.flags & 2u)) {
+        double r = active ? (double)rew : 0.0;
+        const int w = P < 64 ? P : 64;
+        for (int off = w >> 1; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
+        if (active && (i & 63) == 0)
+            atomicAdd(reinterpret_cast<double*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_SUMREW]), r);
+    }
+    __syncthreads();  // all lanes have read red[] and episode[]
+    if (active) {
+        p.pos_x[q] = pos.x; p.pos_y[q] = pos.y;
+        p.vel_x[q] = vel.x; p.vel_y[q] = vel.y;
+        p.pref_x[q] = pref.x; p.pref_y[q] = pref.y;
+        p.nb_count[q] = ncnt;
+        p.obst_count[q] = ocnt;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) p.nb_idx[((size_t)a * K + k) * N + i] = ni[k];
+#pragma unroll
+        for (int k = 0; k < SMAX; ++k)
+            if (k < S) p.obst_idx[((size_t)a * S + k) * N + i] = oi[k];
+        if (i == 0) {
+            unsigned long long* st = p.arena_stats + (size_t)a * ST_STRIDE;
+            if (red[1]) st[ST_COLL] += (unsigned)red[1];
+            if (red[2]) st[ST_OBST_COLL] += (unsigned)red[2];
+            if (red[3]) st[ST_GOALS] += (unsigned)red[3];
+            if (all_done) st[ST_EPISODES] += 1;
+            p.arena_done[a] = all_done ? 1 : 0;
+            p.step_count[a] = do_reset ? 0 : steps;
+            if (do_reset) p.episode[a] = epi + 1;
+        }
+    }
+}
+
+// ============================================================================================
+// reset() for every arena (env.py:461-488): new positions only; velocities, targets and the
+// neighbour lists of the last step stay.
+// ============================================================================================
+__global__ void reset_kernel(const StepArgs p) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= p.A * p.N) return;
+    const int a = q / p.N, i = q - a * p.N;
+    V2 pos;
+    if (p.reset_px) {
+        pos = mk(p.reset_px[q], p.reset_py[q]);
+    } else {
+        double u0, u1;
+        rng2(p.seed, p.arena_offset + a, i, RNG_RESET, (uint32_t)p.episode[a], &u0, &u1);
+        pos = mk((float)uniform64((double)p.spawn_x0, (double)p.spawn_x1, u0),
+                 (float)uniform64((double)p.spawn_y0, (double)p.spawn_y1, u1));
+    }
+    double dx, dy;
+    pref_dir64(pos.x, pos.y, p.goal_x[q], p.goal_y[q], &dx, &dy);
+    p.pos_x[q] = pos.x; p.pos_y[q] = pos.y;
+    p.pref_x[q] = (float)dx; p.pref_y[q] = (float)dy;
+    p.agent_done[q] = 0;
+}
+__global__ void reset_arena_kernel(const StepArgs p) {  // after reset_kernel: per-arena counters
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= p.A) return;
+    p.step_count[a] = 0;
+    p.arena_done[a] = 0;
+    p.episode[a] += 1;
+}
+
+// ============================================================================================
+// Laser observation (env.py:231-318, utils.py:5-113).
+// 16 lanes per agent = one lane per ray; a wave covers 4 agents.  The 16 lanes first build the
+// agent's segment list (8 octagon chords per ORCA agent neighbour + one segment per ORCA obstacle
+// neighbour), rotated into the goal-aligned frame, in LDS; then every lane casts its ray over
+// all segments (broadcast LDS reads) and writes its 4 floats: 16 lanes x 16 B = the agent's
+// 256-B observation row, so a wave stores 1 KiB contiguously.
+// ============================================================================================
+struct ObsArgs {
+    const float *pos_x, *pos_y, *vel_x, *vel_y, *goal_x, *goal_y;
+    const int *nb_count, *nb_idx, *obst_count, *obst_idx;
+    const ObstDev* obst;
+    float* obs;
+    int A, N, K, S;
+    float rays[32];  // env.py:321-332
+    float oct[32];   // env.py:335-350
+};
+
+constexpr int OBS_BS = 256;
+constexpr int OBS_APB = OBS_BS / 16;  // agents per block
+
+__host__ __device__ inline size_t obs_lds_bytes(int K, int S) {
+    return (size_t)OBS_APB * ((size_t)(8 * K + S) * 32 + 32);  // +32: stagger against bank conflicts
+}
+
+__global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
+    extern __shared__ float4 smem4[];
+    const int tid = threadIdx.x;
+    const int g = tid >> 4, r = tid & 15;
+    const long long q = (long long)blockIdx.x * OBS_APB + g;
+    const int total = p.A * p.N;
+    const bool active = q < total;
+    const int N = p.N, K = p.K, S = p.S;
+    const int mcap = 8 * K + S;
+    float4* seg = smem4 + (size_t)g * (2 * mcap + 2);  // per agent: mcap x (2 float4) + stagger
+
+    int M = 0;
+    if (active) {
+        const int a = (int)(q / N), i = (int)(q - (long long)a * N);
+        const int nn = p.nb_count[q], ns = p.obst_count[q];
+        M = 8 * nn + ns;
+        if (M > 0) {
+            const float mx = p.pos_x[q], my = p.pos_y[q];
+            double ox, oy;  // env.py:236: orientation = comp_pref_vel of the current state
+            pref_dir64(mx, my, p.goal_x[q], p.goal_y[q], &ox, &oy);
+            const float c = (float)ox, s = (float)(-oy);  // utils.py:48-51 for a unit vector
+            for (int m = r; m < M; m += 16) {
+                float x1, y1, x2, y2, vx, vy;
+                if (m < 8 * nn) {  // env.py:283-294
+                    const int k = m >> 3, e = m & 7;
+                    const int nb = p.nb_idx[((size_t)a * K + k) * N + i];
+                    const size_t qn = (size_t)a * N + nb;
+                    const float rx = p.pos_x[qn] - mx, ry = p.pos_y[qn] - my;
+                    x1 = p.oct[4 * e] + rx; y1 = p.oct[4 * e + 1] + ry;
+                    x2 = p.oct[4 * e + 2] + rx; y2 = p.oct[4 * e + 3] + ry;
+                    vx = p.vel_x[qn]; vy = p.vel_y[qn];  // env.py:252
+                } else {  // env.py:305-315
+                    const int v1 = p.obst_idx[((size_t)a * S + (m - 8 * nn)) * N + i];
+                    const ObstDev o1 = load_obst(p.obst, v1);
+                    const ObstDev o2 = load_obst(p.obst, o1.next);
+                    x1 = o1.px - mx; y1 = o1.py - my;
+                    x2 = o2.px - mx; y2 = o2.py - my;
+                    vx = 0.0f; vy = 0.0f;
+                }
+                const float lvx = x1 + vx, lvy = y1 + vy;                  // utils.py:57
+                const float r1x = c * x1 - s * y1, r1y = s * x1 + c * y1;  // utils.py:59
+                const float r2x = c * x2 - s * y2, r2y = s * x2 + c * y2;  // utils.py:60
+                const float rvx = c * lvx - s * lvy, rvy = s * lvx + c * lvy;  // utils.py:61
+                const float s32x = r2x - r1x, s32y = r2y - r1y;            // utils.py:11-12
+                const float s02x = 0.0f - r1x, s02y = 0.0f - r1y;          // utils.py:19-20
+                const float t_numer = s32x * s02y - s32y * s02x;           // utils.py:26
+                seg[2 * m] = make_float4(s02x, s02y, s32x, s32y);
+                seg[2 * m + 1] = make_float4(t_numer, rvx - r1x, rvy - r1y, 0.0f);  // utils.py:62
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const float INF = __int_as_float(0x7f800000);
+    const float s10x = p.rays[2 * r] - 0.0f, s10y = p.rays[2 * r + 1] - 0.0f;  // utils.py:9-10
+    float best = INF, bx = 0.0f, by = 0.0f;
+    int bi = -1;
+    for (int m = 0; m < M; ++m) {
+        const float4 A0 = seg[2 * m];
+        const float denom = s10x * A0.w - A0.z * s10y;                 // utils.py:14
+        if (denom == 0.0f) continue;
+        const bool dpos = denom > 0.0f;
+        const float s_numer = s10x * A0.y - s10y * A0.x;               // utils.py:21
+        if ((s_numer < 0.0f) == dpos) continue;
+        const float t_numer = seg[2 * m + 1].x;
+        if ((t_numer < 0.0f) == dpos) continue;
+        if (((s_numer > denom) == dpos) || ((t_numer > denom) == dpos)) continue;
+        const float t = t_numer / denom;                               // utils.py:34
+        const float hx = 0.0f + t * s10x, hy = 0.0f + t * s10y;        // utils.py:36-37
+        const float d = sqrtf(hx * hx + hy * hy);                      // utils.py:38
+        if (d < best) { best = d; bx = hx; by = hy; bi = m; }          // first minimum wins
+    }
+    float vx = 0.0f, vy = 0.0f;
+    if (bi >= 0 && !(bx == 0.0f && by == 0.0f)) {                      // utils.py:103
+        const float4 B = seg[2 * bi + 1];
+        vx = B.y; vy = B.z;
+    }
+    reinterpret_cast<float4*>(p.obs)[q * 16 + r] = make_float4(bx, by, vx, vy);
+}
+
+// ---- diagnostics for the numerics contract ----
+__global__ void debug_math_kernel(int op, const void* in, void* out, int n, uint64_t seed) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    if (op == 0) {
+        ((float*)out)[t] = sqrtf(((const float*)in)[t]);
+    } else if (op == 1) {
+        ((float*)out)[t] = ((const float*)in)[2 * t] / ((const float*)in)[2 * t + 1];
+    } else if (op == 2) {
+        double s, c;
+        sincos64(((const double*)in)[t], &s, &c);
+        ((double*)out)[2 * t] = s; ((double*)out)[2 * t + 1] = c;
+    } else if (op == 3) {
+        const float* f = (const float*)in + 4 * t;
+        double x, y;
+        pref_dir64(f[0], f[1], f[2], f[3], &x, &y);
+        ((double*)out)[2 * t] = x; ((double*)out)[2 * t + 1] = y;
+    } else if (op == 4) {
+        const uint32_t* u = (const uint32_t*)in + 4 * t;
+        double a, b;
+        rng2(seed, (int64_t)u[0], (int)u[1], (int)u[2], u[3], &a, &b);
+        ((double*)out)[2 * t] = a; ((double*)out)[2 * t + 1] = b;
+    }
+}
+
+}  // namespace ca

@@ -1,0 +1,99 @@
+// ca_math.h -- deterministic scalar helpers used by the HIP kernels and by the host-side scenario
+// generators of libcaenv.so.  Every function is a fixed sequence of single IEEE operations
+// (the library is built with -ffp-contract=off), so host and device agree bit for bit and the
+// results do not depend on any libm.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CA_HD __host__ __device__ __forceinline__
+
+namespace ca {
+
+// ---- fp32 2-vectors; operation order is that of the RVO2 library's Vector2 ----
+struct V2 {
+    float x, y;
+};
+CA_HD V2 mk(float x, float y) { V2 v; v.x = x; v.y = y; return v; }
+CA_HD V2 operator+(V2 a, V2 b) { return mk(a.x + b.x, a.y + b.y); }
+CA_HD V2 operator-(V2 a, V2 b) { return mk(a.x - b.x, a.y - b.y); }
+CA_HD V2 operator-(V2 a) { return mk(-a.x, -a.y); }
+CA_HD V2 operator*(float s, V2 a) { return mk(s * a.x, s * a.y); }
+CA_HD V2 operator*(V2 a, float s) { return mk(a.x * s, a.y * s); }
+CA_HD float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+CA_HD float det(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
+CA_HD float absSq(V2 a) { return a.x * a.x + a.y * a.y; }
+CA_HD float sqr(float a) { return a * a; }
+CA_HD float vabs(V2 a) { return sqrtf(absSq(a)); }
+CA_HD V2 vdiv(V2 a, float s) {  // vector / scalar multiplies by the reciprocal
+    const float inv = 1.0f / s;
+    return mk(a.x * inv, a.y * inv);
+}
+CA_HD V2 normalize(V2 a) { return vdiv(a, vabs(a)); }
+CA_HD float leftOf(V2 a, V2 b, V2 c) { return det(a - c, b - a); }
+CA_HD float distSqPointSegment(V2 a, V2 b, V2 c) {
+    const float r = dot(c - a, b - a) / absSq(b - a);
+    if (r < 0.0f) return absSq(c - a);
+    if (r > 1.0f) return absSq(c - b);
+    return absSq(c - (a + r * (b - a)));
+}
+
+// ---- sin/cos in fp64: quadrant reduction + fixed polynomials (|a| <~ 1e5, error <~ 2e-16) ----
+CA_HD void sincos64(double a, double* s, double* c) {
+    const double kd = floor(a * 6.36619772367581382433e-01 + 0.5);
+    const double r = (a - kd * 1.57079632673412561417e+00) - kd * 6.07710050650619224932e-11;
+    const double z = r * r;
+    const double sp = r + (z * r) * (-1.66666666666666324348e-01 +
+                      z * (8.33333333332248946124e-03 +
+                      z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 +
+                      z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
+    const double cp = 1.0 - (0.5 * z - (z * z) * (4.16666666666666019037e-02 +
+                      z * (-1.38888888888741095749e-03 +
+                      z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 +
+                      z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))))));
+    const int q = (int)((long long)kd & 3);
+    *s = (q == 0) ? sp : (q == 1) ? cp : (q == 2) ? -sp : -cp;
+    *c = (q == 0) ? cp : (q == 1) ? -sp : (q == 2) ? -cp : sp;
+}
+
+// env.py:156-162 comp_pref_vel: unit vector from pos to goal in fp64; zero vector -> (1, 0)
+CA_HD void pref_dir64(float px, float py, float gx, float gy, double* ox, double* oy) {
+    const double dx = (double)gx - (double)px;
+    const double dy = (double)gy - (double)py;
+    const bool z = (dx == 0.0 && dy == 0.0);
+    const double len = z ? 1.0 : sqrt(dx * dx + dy * dy);
+    *ox = z ? 1.0 : dx / len;
+    *oy = z ? 0.0 : dy / len;
+}
+
+// ---- Philox4x32-10 counter-based RNG ----
+CA_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+CA_HD void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                      uint32_t* o) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+enum { RNG_POS = 0, RNG_HEADING = 1, RNG_GOAL = 2, RNG_REGOAL = 3, RNG_RESET = 4 };
+// two uniforms in [0,1) with 53 random bits each; stream = (seed, global arena, agent, purpose, seq)
+CA_HD void rng2(uint64_t seed, int64_t arena, int agent, int purpose, uint32_t seq, double* u0, double* u1) {
+    uint32_t w[4];
+    const uint64_t g = (uint64_t)arena;
+    philox4x32((uint32_t)g, (uint32_t)agent, (uint32_t)purpose, seq, (uint32_t)seed,
+               (uint32_t)(seed >> 32) + (uint32_t)(g >> 32), w);
+    const double k = 1.0 / 9007199254740992.0;
+    *u0 = (double)(((uint64_t)(w[0] >> 5) << 26) | (uint64_t)(w[1] >> 6)) * k;
+    *u1 = (double)(((uint64_t)(w[2] >> 5) << 26) | (uint64_t)(w[3] >> 6)) * k;
+}
+CA_HD double uniform64(double a, double b, double u) { return a + (b - a) * u; }
+
+}  // namespace ca

@@ -1,0 +1,214 @@
+"""Batched collision-avoidance environment on one MI355X: A independent arenas x N agents.
+
+This is the vectorised form of the reference's Collision_Avoidance_Env (reference
+collision_avoidance/envs/collision_avoidence_env.py:23-488): the same reset()/step()/orca_step()
+semantics applied to every arena at once by the HIP kernels behind the C ABI of
+include/ca_env.h.  PyTorch is used only to hand tensors across (observations out, actions in);
+without it the same calls work on numpy arrays through host copies.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, scenarios
+
+try:  # plumbing only
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+_I32_FIELDS = {_lib.FLD_AGENT_DONE, _lib.FLD_ARRIVE_STEP, _lib.FLD_NB_COUNT, _lib.FLD_NB_IDX,
+               _lib.FLD_OBST_COUNT, _lib.FLD_OBST_IDX, _lib.FLD_STEP_COUNT, _lib.FLD_ARENA_DONE,
+               _lib.FLD_EPISODE, _lib.FLD_REGOAL_COUNT}
+_ARENA_FIELDS = {_lib.FLD_STEP_COUNT, _lib.FLD_ARENA_DONE, _lib.FLD_EPISODE}
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class VecCollisionAvoidanceEnv:
+    """A arenas x N agents advanced per call.
+
+    scenario: "crowd" | "circle" | "doorway" (scenarios.py) or None to leave the state unset.
+    params:   dict of ca_config fields; defaults are the reference env's constants.
+    use_torch: hand observations/rewards out as torch tensors on the device (zero-copy for the
+               observation) and accept device tensors as actions.  False: numpy in/out.
+    """
+
+    def __init__(self, n_arenas, n_agents, scenario="crowd", params=None, device=0, seed=0,
+                 arena_offset=0, max_obst_neighbors=None, use_torch=None, obstacles="scenario"):
+        self.L = _lib.load()
+        self.A, self.N = int(n_arenas), int(n_agents)
+        p = scenarios.env_params()
+        if params:
+            p.update(params)
+        if obstacles == "scenario":
+            polys = scenarios.obstacles(scenario, n_agents, p["radius"]) if scenario is not None else []
+        else:
+            polys = list(obstacles or [])
+        n_edges = sum(len(q) for q in polys)
+        if max_obst_neighbors is None:
+            max_obst_neighbors = max(1, min(_lib.MAX_OBST_NEIGHBORS, n_edges))
+        self.cfg = _lib.Config(n_arenas=self.A, n_agents=self.N, arena_offset=arena_offset, seed=seed,
+                               max_obst_neighbors=max_obst_neighbors, **p)
+        self.K, self.S = self.cfg.max_neighbors, self.cfg.max_obst_neighbors
+        self.device = int(device)
+        self.use_torch = (torch is not None and torch.cuda.is_available()) if use_torch is None else bool(use_torch)
+        stream = None
+        if self.use_torch:
+            torch.cuda.set_device(self.device)
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        h = C.c_void_p()
+        rc = self.L.ca_create(C.byref(self.cfg), self.device, stream, C.byref(h))
+        _lib.check(self.L, None, rc, "ca_create")
+        self.h = h
+        self._obs_t = None
+        if self.use_torch:
+            dev = torch.device("cuda", self.device)
+            self._obs_t = torch.zeros((self.A, self.N, _lib.OBS_DIM), dtype=torch.float32, device=dev)
+            self._call("ca_bind_obs", self.h, C.c_void_p(self._obs_t.data_ptr()), self._obs_t.numel() * 4)
+            self._rew_t = torch.zeros((self.A, self.N), dtype=torch.float32, device=dev)
+            self._done_t = torch.zeros((self.A,), dtype=torch.int32, device=dev)
+            self._act_t = torch.zeros((self.A, self.N), dtype=torch.float32, device=dev)
+        self.set_obstacles(polys)
+        if scenario is not None:
+            self.init_scenario(scenario)
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    def _call(self, name, *args):
+        rc = getattr(self.L, name)(*args)
+        _lib.check(self.L, self.h, rc, name)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ca_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _shape_dtype(self, field):
+        dt = np.int32 if field in _I32_FIELDS else np.float32
+        if field in _ARENA_FIELDS:
+            return (self.A,), dt
+        if field == _lib.FLD_NB_IDX:
+            return (self.A, max(self.K, 1), self.N), dt
+        if field == _lib.FLD_OBST_IDX:
+            return (self.A, self.S, self.N), dt
+        if field == _lib.FLD_OBS:
+            return (self.A, self.N, _lib.OBS_DIM), dt
+        return (self.A, self.N), dt
+
+    def get(self, field):
+        """Host copy of a state field (synchronises the stream)."""
+        shape, dt = self._shape_dtype(field)
+        out = np.empty(shape, dt)
+        self._call("ca_get", self.h, field, _ptr(out), out.nbytes, 0)
+        return out
+
+    def set(self, field, arr):
+        shape, dt = self._shape_dtype(field)
+        a = np.ascontiguousarray(np.asarray(arr, dt).reshape(shape))
+        self._call("ca_set", self.h, field, _ptr(a), a.nbytes, 0)
+
+    def neighbor_lists(self):
+        """(count [A,N], idx [A,N,K]) of the ORCA agent neighbours of the last step, nearest first."""
+        return self.get(_lib.FLD_NB_COUNT), np.transpose(self.get(_lib.FLD_NB_IDX), (0, 2, 1))[:, :, :self.K]
+
+    def obstacle_neighbor_lists(self):
+        return self.get(_lib.FLD_OBST_COUNT), np.transpose(self.get(_lib.FLD_OBST_IDX), (0, 2, 1))
+
+    def set_obstacles(self, polys):
+        polys = [np.asarray(q, np.float32).reshape(-1, 2) for q in polys]
+        verts = np.ascontiguousarray(np.concatenate(polys) if polys else np.zeros((0, 2), np.float32))
+        sizes = np.asarray([len(q) for q in polys], np.int32)
+        self._call("ca_set_obstacles", self.h, _ptr(verts), _ptr(sizes), len(polys))
+
+    def init_scenario(self, scenario):
+        sid = scenarios.SCENARIO_IDS[scenario] if isinstance(scenario, str) else int(scenario)
+        self._call("ca_init_scenario", self.h, sid)
+
+    def sync(self):
+        self._call("ca_sync", self.h)
+
+    def stats(self):
+        s = _lib.Stats()
+        self._call("ca_get_stats", self.h, C.byref(s))
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._call("ca_reset_stats", self.h)
+
+    def launch_info(self):
+        v = [C.c_int32() for _ in range(4)]
+        self._call("ca_launch_info", self.h, *[C.byref(x) for x in v])
+        return dict(block=v[0].value, grid=v[1].value, lds_bytes=v[2].value, obs_grid=v[3].value)
+
+    # ---- the environment API ----------------------------------------------------------------------
+    def _obs_out(self):
+        return self._obs_t if self.use_torch else self.get(_lib.FLD_OBS)
+
+    def reset(self, pos_x=None, pos_y=None, with_obs=True):
+        """reference reset() (env.py:461-488) for every arena.  pos_x/pos_y [A,N]: explicit new
+        positions (numpy or device tensor); default: drawn from the spawn box."""
+        flags = _lib.F_OBS if with_obs else 0
+        if pos_x is None:
+            self._call("ca_reset", self.h, None, None, 0, flags)
+        elif torch is not None and isinstance(pos_x, torch.Tensor):
+            px = pos_x.to(dtype=torch.float32).contiguous()
+            py = pos_y.to(dtype=torch.float32).contiguous()
+            self._call("ca_reset", self.h, C.c_void_p(px.data_ptr()), C.c_void_p(py.data_ptr()), 1, flags)
+            self.sync()
+        else:
+            px = np.ascontiguousarray(np.asarray(pos_x, np.float32).reshape(self.A, self.N))
+            py = np.ascontiguousarray(np.asarray(pos_y, np.float32).reshape(self.A, self.N))
+            self._call("ca_reset", self.h, _ptr(px), _ptr(py), 0, flags)
+        return self._obs_out() if with_obs else None
+
+    def step(self, actions, with_obs=True, stats=False, autoreset=False):
+        """reference step(action) (env.py:367-416) for every arena.
+        actions [A,N] heading offsets (rad).  Returns (obs [A,N,64], rewards [A,N], dones [A], {})."""
+        flags = (_lib.F_OBS if with_obs else 0) | (_lib.F_STATS if stats else 0) | \
+                (_lib.F_AUTORESET if autoreset else 0)
+        if self.use_torch:
+            if not isinstance(actions, torch.Tensor):
+                actions = torch.as_tensor(np.asarray(actions, np.float32).reshape(self.A, self.N))
+            self._act_t.copy_(actions.reshape(self.A, self.N), non_blocking=True)
+            self._call("ca_step", self.h, C.c_void_p(self._act_t.data_ptr()), flags)
+            self._call("ca_get", self.h, _lib.FLD_REWARD, C.c_void_p(self._rew_t.data_ptr()),
+                       self._rew_t.numel() * 4, 1)
+            self._call("ca_get", self.h, _lib.FLD_ARENA_DONE, C.c_void_p(self._done_t.data_ptr()),
+                       self._done_t.numel() * 4, 1)
+            return (self._obs_t if with_obs else None), self._rew_t, self._done_t, {}
+        a = np.ascontiguousarray(np.asarray(actions, np.float32).reshape(self.A, self.N))
+        self._call("ca_step_host", self.h, _ptr(a), flags)
+        return (self.get(_lib.FLD_OBS) if with_obs else None), self.get(_lib.FLD_REWARD), \
+            self.get(_lib.FLD_ARENA_DONE), {}
+
+    def orca_step(self, with_obs=False, stats=False, no_done=False, autoreset=False):
+        """reference orca_step (env.py:447-458 with no_done=True; ALAN_true.py:631-636 + done test)."""
+        flags = (_lib.F_OBS if with_obs else 0) | (_lib.F_STATS if stats else 0) | \
+                (_lib.F_NODONE if no_done else 0) | (_lib.F_AUTORESET if autoreset else 0)
+        self._call("ca_orca_step", self.h, flags)
+        return self._obs_out() if with_obs else None
+
+    def observe(self):
+        """reference _get_obs() (env.py:231-277) on the current state."""
+        self._call("ca_observe", self.h)
+        return self._obs_out()
+
+    def rollout(self, steps, with_obs=False, stats=False, autoreset=False):
+        flags = (_lib.F_OBS if with_obs else 0) | (_lib.F_STATS if stats else 0) | \
+                (_lib.F_AUTORESET if autoreset else 0)
+        self._call("ca_rollout", self.h, int(steps), flags)
+
+    def state(self):
+        names = dict(pos_x=_lib.FLD_POS_X, pos_y=_lib.FLD_POS_Y, vel_x=_lib.FLD_VEL_X, vel_y=_lib.FLD_VEL_Y,
+                     pref_x=_lib.FLD_PREF_X, pref_y=_lib.FLD_PREF_Y, goal_x=_lib.FLD_GOAL_X,
+                     goal_y=_lib.FLD_GOAL_Y, agent_done=_lib.FLD_AGENT_DONE,
+                     step_count=_lib.FLD_STEP_COUNT, arena_done=_lib.FLD_ARENA_DONE)
+        return {k: self.get(v) for k, v in names.items()}

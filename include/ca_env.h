@@ -1,0 +1,174 @@
+/*
+ * ca_env.h -- C ABI of libcaenv.so: the MI355X (gfx950) batched collision-avoidance environment.
+ *
+ * This is the drop-in boundary for the hot path of navallo/collision_avoidance: one call
+ * advances A independent arenas x N agents through what the reference does per agent in Python
+ * plus per-scalar calls into the external `rvo2` extension.  Citations (file:line) are into
+ * /root/reference/collision_avoidance/ : env.py = envs/collision_avoidence_env.py,
+ * utils.py = envs/utils.py, ALAN = ALAN/ALAN_true.py.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success, a negative CA_E* code on failure;
+ *     ca_last_error() returns the message of the last failure on that handle (NULL handle: of the
+ *     last failed ca_create on this thread).
+ *   - a handle is bound to one HIP device and one stream; calls are asynchronous on that stream
+ *     unless stated otherwise.  A handle is not thread-safe; distinct handles are independent.
+ *   - all per-agent arrays are struct-of-arrays fp32/int32 of shape [A, N] (agent index fastest).
+ *   - there is NO CPU fallback: without a HIP device ca_create fails with CA_ENODEV.
+ */
+#ifndef CA_ENV_H
+#define CA_ENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CA_OBS_DIM 64 /* env.py:34,53: 16 rays x (hit x, hit y, vel x, vel y) */
+#define CA_N_RAYS 16
+#define CA_MAX_NEIGHBORS 16      /* largest supported max_neighbors       */
+#define CA_MAX_OBST_NEIGHBORS 8  /* largest supported max_obst_neighbors  */
+#define CA_MAX_AGENTS 1024       /* one workgroup owns one arena          */
+
+/* error codes */
+#define CA_OK 0
+#define CA_EINVAL (-1)
+#define CA_ENODEV (-2)
+#define CA_EHIP (-3)
+#define CA_ESIZE (-4)
+#define CA_ERANGE (-5)
+
+/* done_mode: who decides that an agent has finished */
+#define CA_DONE_XLESS 0  /* env.py:352-365: pos.x < done_x_thresh -> done, goal <- goal2      */
+#define CA_DONE_GOAL 1   /* ALAN:547-566: |pos - goal| < 2 r -> done, goal <- goal2           */
+#define CA_DONE_REGOAL 2 /* synthetic workload: |pos - goal| < 2 r -> draw a new goal         */
+
+/* step flags */
+#define CA_F_OBS 1u       /* write the laser observation (env.py:231-277, utils.py:42-113)     */
+#define CA_F_STATS 2u     /* count collisions (build-defined)                   */
+#define CA_F_AUTORESET 4u /* arenas that finished are reset (env.py:461-488) inside the call   */
+#define CA_F_NODONE 8u    /* ca_orca_step only: no done test, no step counter (env.py:447-450) */
+
+/* scenarios for ca_init_scenario */
+#define CA_SCN_CROWD 0   /* ALAN:270-294 random start / random goal                            */
+#define CA_SCN_CIRCLE 1  /* ALAN:297-330 circle swap                                           */
+#define CA_SCN_DOORWAY 2 /* env.py:77-123 the reference env's own world                        */
+
+/* fields for ca_get / ca_set / ca_field_ptr */
+enum ca_field {
+    CA_FLD_POS_X = 0, CA_FLD_POS_Y, CA_FLD_VEL_X, CA_FLD_VEL_Y, CA_FLD_PREF_X, CA_FLD_PREF_Y,
+    CA_FLD_GOAL_X, CA_FLD_GOAL_Y, CA_FLD_GOAL2_X, CA_FLD_GOAL2_Y,
+    CA_FLD_REWARD,       /* f32 [A,N]                                             */
+    CA_FLD_AGENT_DONE,   /* i32 [A,N]                                             */
+    CA_FLD_ARRIVE_STEP,  /* i32 [A,N]                                             */
+    CA_FLD_NB_COUNT,     /* i32 [A,N]   ORCA agent-neighbour count (read-only)    */
+    CA_FLD_NB_IDX,       /* i32 [A,K,N] ORCA agent neighbours, nearest first      */
+    CA_FLD_OBST_COUNT,   /* i32 [A,N]                                             */
+    CA_FLD_OBST_IDX,     /* i32 [A,S,N] ORCA obstacle-edge neighbours             */
+    CA_FLD_OBS,          /* f32 [A,N,64]                                          */
+    CA_FLD_STEP_COUNT,   /* i32 [A]                                               */
+    CA_FLD_ARENA_DONE,   /* i32 [A]                                               */
+    CA_FLD_EPISODE,      /* i32 [A]                                               */
+    CA_FLD_REGOAL_COUNT, /* i32 [A,N]                                             */
+    CA_FLD__COUNT
+};
+
+/* Replaces the constants the reference hard-codes in Collision_Avoidance_Env.__init__
+ * (env.py:27-44), the literal at env.py:130, and the per-call arguments of
+ * rvo2.PyRVOSimulator / addAgent (env.py:62-68, 126-133; ALAN:22-28). */
+typedef struct ca_config {
+    int32_t n_arenas;           /* arenas owned by this handle (this GPU's shard)             */
+    int32_t n_agents;           /* agents per arena, 1..CA_MAX_AGENTS                         */
+    int64_t arena_offset;       /* global id of arena 0: keys the scenario RNG, so results do
+                                   not depend on how arenas are sharded over GPUs             */
+    uint64_t seed;
+    double reward_scale;        /* env.py:396 (0.3); ALAN:47 gamma (0.6)                      */
+    float time_step;            /* env.py:27                                                  */
+    float neighbor_dist;        /* env.py:28 / ALAN:16                                        */
+    int32_t max_neighbors;      /* env.py:29 / ALAN:17, 0..CA_MAX_NEIGHBORS                   */
+    float time_horizon;         /* env.py:30                                                  */
+    float time_horizon_obst;    /* env.py:130                                                 */
+    float radius;               /* env.py:31                                                  */
+    float max_speed;            /* env.py:32                                                  */
+    int32_t max_obst_neighbors; /* capacity of the obstacle-neighbour list, 1..CA_MAX_OBST_NEIGHBORS;
+                                   overflow is counted in ca_stats.obst_overflow               */
+    int32_t max_step;           /* env.py:44; <= 0: no cap                                    */
+    int32_t done_mode;
+    float done_x_thresh;        /* env.py:359                                                 */
+    float spawn_x0, spawn_x1, spawn_y0, spawn_y1; /* reset() spawn box, env.py:478            */
+    float goal_x0, goal_x1, goal_y0, goal_y1;     /* CA_DONE_REGOAL draw box                  */
+} ca_config;
+
+typedef struct ca_stats {
+    uint64_t agent_steps;
+    uint64_t episodes;
+    uint64_t collisions;      /* overlapping agent pairs after the update, summed over steps  */
+    uint64_t obst_collisions; /* agents overlapping an obstacle edge, summed over steps       */
+    uint64_t goals_reached;
+    uint64_t obst_overflow;
+    double sum_reward;
+} ca_stats;
+
+typedef struct ca_env ca_env;
+
+/* Replaces Collision_Avoidance_Env.__init__ + rvo2.PyRVOSimulator(...) (env.py:26-74, 62-68).
+ * device: HIP device ordinal.  stream: a hipStream_t to run on (e.g. PyTorch's current stream),
+ * or NULL to let the handle create its own. */
+int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out);
+int ca_destroy(ca_env* env);
+const char* ca_last_error(const ca_env* env);
+
+/* Replaces sim.addObstacle + sim.processObstacles (env.py:118-123, 143-149): the same polygons
+ * for every arena.  verts_xy: host array [sum(poly_sizes), 2]. */
+int ca_set_obstacles(ca_env* env, const float* verts_xy, const int32_t* poly_sizes, int32_t n_poly);
+
+/* Replaces _init_world's agent loop (env.py:86-97) / ALAN's scenario generators (ALAN:270-330). */
+int ca_init_scenario(ca_env* env, int32_t scenario);
+
+/* Replaces the per-scalar getters/setters (sim.getAgentPosition, setAgentPosition, ...
+ * env.py:157, 237, 479): whole-array copies.  *_is_device: the caller's pointer is device memory. */
+int ca_set(ca_env* env, int32_t field, const void* src, size_t bytes, int32_t src_is_device);
+int ca_get(ca_env* env, int32_t field, void* dst, size_t bytes, int32_t dst_is_device);
+/* Zero-copy view of a field's device buffer (valid until ca_destroy / ca_bind_obs). */
+int ca_field_ptr(ca_env* env, int32_t field, void** dev_ptr, size_t* bytes);
+/* Let the caller own the observation buffer (e.g. a torch tensor [A,N,64] f32 on this device). */
+int ca_bind_obs(ca_env* env, void* dev_ptr, size_t bytes);
+
+/* Replaces reset() (env.py:461-488).  pos_x/pos_y: device or host arrays [A,N] with the new
+ * positions, or NULL to draw them from the spawn box with the counter-based RNG. */
+int ca_reset(ca_env* env, const float* pos_x, const float* pos_y, int32_t pos_is_device, uint32_t flags);
+
+/* Replaces step(action) (env.py:367-416).  actions: DEVICE array [A,N] f32 of heading offsets. */
+int ca_step(ca_env* env, const float* actions, uint32_t flags);
+/* Same, with the actions in HOST memory (copied to the device on the handle's stream). */
+int ca_step_host(ca_env* env, const float* actions_host, uint32_t flags);
+/* Replaces orca_step (env.py:447-458; ALAN:631-636 + the done test of ALAN:118-121). */
+int ca_orca_step(ca_env* env, uint32_t flags);
+/* Replaces _get_obs() alone (env.py:231-277): recompute the observation of the current state. */
+int ca_observe(ca_env* env);
+/* `steps` consecutive ca_orca_step calls without returning to the host. */
+int ca_rollout(ca_env* env, int32_t steps, uint32_t flags);
+
+/* Blocks until the stream is idle, then returns the counters accumulated so far. */
+int ca_get_stats(ca_env* env, ca_stats* out);
+int ca_reset_stats(ca_env* env);
+int ca_sync(ca_env* env);
+
+/* Diagnostics for the numerics contract tests: evaluates device primitives on n inputs.
+ * op 0: sqrtf(x)            in f32[n]        out f32[n]
+ * op 1: a / b               in f32[2n]       out f32[n]
+ * op 2: sincos64(x)         in f64[n]        out f64[2n]
+ * op 3: pref_dir64          in f32[4n]       out f64[2n]
+ * op 4: philox4x32 uniform  in u32[4n]       out f64[2n]   (key = seed of the handle)
+ * Host pointers. */
+int ca_debug_math(ca_env* env, int32_t op, const void* in, void* out, int32_t n);
+
+/* Launch geometry chosen for this handle (for reports): threads per block, blocks, LDS bytes. */
+int ca_launch_info(ca_env* env, int32_t* block, int32_t* grid, int32_t* lds_bytes, int32_t* obs_grid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

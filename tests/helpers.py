@@ -1,0 +1,91 @@
+"""Shared helpers for the parity tests: build the HIP environment and the CPU oracle in the same
+configuration and compare them field by field."""
+import numpy as np
+
+from collision_avoidance_amd import scenarios
+from oracle import oracle as o
+
+SCN = {"crowd": o.SCN_CROWD, "circle": o.SCN_CIRCLE, "doorway": o.SCN_DOORWAY}
+
+
+def scenario_params(scenario, n_agents, **over):
+    if scenario == "doorway":
+        p = scenarios.env_params()
+    else:
+        p = scenarios.alan_params(n_agents, scenario)
+    p.update(over)
+    return p
+
+
+def make_oracle(A, N, scenario, params, seed=0, arena_offset=0, max_obst_neighbors=None, polys=None):
+    polys = scenarios.obstacles(scenario, N, params["radius"]) if polys is None else polys
+    n_edges = sum(len(q) for q in polys)
+    S = max(1, min(8, n_edges)) if max_obst_neighbors is None else max_obst_neighbors
+    cfg = o.make_config(n_arenas=A, n_agents=N, seed=seed, arena_offset=arena_offset,
+                        max_obst_neighbors=S, **params)
+    env = o.OracleEnv(cfg)
+    env.set_obstacles(polys)
+    env.init_scenario(SCN[scenario])
+    return env
+
+
+def make_gpu(A, N, scenario, params, seed=0, arena_offset=0, max_obst_neighbors=None, use_torch=False,
+             polys=None):
+    from collision_avoidance_amd.vec_env import VecCollisionAvoidanceEnv
+    return VecCollisionAvoidanceEnv(A, N, scenario=scenario, params=params, seed=seed,
+                                    arena_offset=arena_offset, max_obst_neighbors=max_obst_neighbors,
+                                    use_torch=use_torch,
+                                    obstacles="scenario" if polys is None else polys)
+
+
+def _eq(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype.kind == "f":
+        ok = np.array_equal(a.view(np.uint32), b.view(np.uint32)) or np.array_equal(a, b, equal_nan=True)
+    else:
+        ok = np.array_equal(a, b)
+    if not ok:
+        bad = np.argwhere(~((a == b) | (np.isnan(a) & np.isnan(b)) if a.dtype.kind == "f" else (a == b)))
+        first = tuple(bad[0])
+        raise AssertionError("%s differs at %d of %d entries; first %s: gpu=%r oracle=%r"
+                             % (what, len(bad), a.size, first, a[first], b[first]))
+
+
+def assert_state_equal(gpu, orc, what="", obs=False, reward=False, lists=True):
+    """Bit-exact comparison of the HIP environment with the oracle (ORC_PREC_F32)."""
+    from collision_avoidance_amd import _lib
+    pairs = [("pos_x", _lib.FLD_POS_X, o.FLD_POS_X), ("pos_y", _lib.FLD_POS_Y, o.FLD_POS_Y),
+             ("vel_x", _lib.FLD_VEL_X, o.FLD_VEL_X), ("vel_y", _lib.FLD_VEL_Y, o.FLD_VEL_Y),
+             ("pref_x", _lib.FLD_PREF_X, o.FLD_PREF_X), ("pref_y", _lib.FLD_PREF_Y, o.FLD_PREF_Y),
+             ("goal_x", _lib.FLD_GOAL_X, o.FLD_GOAL_X), ("goal_y", _lib.FLD_GOAL_Y, o.FLD_GOAL_Y),
+             ("agent_done", _lib.FLD_AGENT_DONE, o.FLD_AGENT_DONE),
+             ("step_count", _lib.FLD_STEP_COUNT, o.FLD_STEP_COUNT),
+             ("arena_done", _lib.FLD_ARENA_DONE, o.FLD_ARENA_DONE),
+             ("episode", _lib.FLD_EPISODE, o.FLD_EPISODE),
+             ("regoal_count", _lib.FLD_REGOAL_COUNT, o.FLD_REGOAL_COUNT)]
+    for name, gf, of in pairs:
+        _eq(gpu.get(gf), orc.get(of), "%s %s" % (what, name))
+    if lists:
+        gc, gi = gpu.neighbor_lists()
+        oc, oi = orc.get(o.FLD_NB_COUNT), orc.get(o.FLD_NB_IDX)
+        _eq(gc, oc, what + " nb_count")
+        K = oi.shape[2]
+        mask = np.arange(K)[None, None, :] < oc[:, :, None]
+        _eq(np.where(mask, gi, -1), np.where(mask, oi, -1), what + " nb_idx")
+        gc, gi = gpu.obstacle_neighbor_lists()
+        oc, oi = orc.get(o.FLD_OBST_COUNT), orc.get(o.FLD_OBST_IDX)
+        _eq(gc, oc, what + " obst_count")
+        S = oi.shape[2]
+        mask = np.arange(S)[None, None, :] < oc[:, :, None]
+        _eq(np.where(mask, gi, -1), np.where(mask, oi, -1), what + " obst_idx")
+    if obs:
+        _eq(gpu.get(_lib.FLD_OBS), orc.get(o.FLD_OBS), what + " obs")
+    if reward:
+        _eq(gpu.get(_lib.FLD_REWARD), orc.get(o.FLD_REWARD), what + " reward")
+
+
+def assert_stats_equal(gpu, orc, what=""):
+    g, s = gpu.stats(), orc.stats()
+    for k in ("agent_steps", "episodes", "collisions", "obst_collisions", "goals_reached", "obst_overflow"):
+        assert g[k] == s[k], "%s stats.%s gpu=%d oracle=%d" % (what, k, g[k], s[k])
+    assert abs(g["sum_reward"] - s["sum_reward"]) <= 1e-9 * max(1.0, abs(s["sum_reward"])), (g, s)
