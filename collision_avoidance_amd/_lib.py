@@ -19,7 +19,7 @@ SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY = 0, 1, 2
  FLD_OBST_COUNT, FLD_OBST_IDX, FLD_OBS, FLD_STEP_COUNT, FLD_ARENA_DONE, FLD_EPISODE,
  FLD_REGOAL_COUNT) = range(22)
 
-EXPORTS = ("ca_create", "ca_destroy", "ca_last_error", "ca_set_obstacles", "ca_init_scenario", "ca_set",
+EXPORTS = ("ca_create", "ca_destroy", "ca_last_error", "ca_set_stream", "ca_set_obstacles", "ca_init_scenario", "ca_set",
            "ca_get", "ca_field_ptr", "ca_bind_obs", "ca_reset", "ca_step", "ca_step_host", "ca_orca_step", "ca_observe", "ca_rollout",
            "ca_get_stats", "ca_reset_stats", "ca_sync", "ca_debug_math", "ca_launch_info")
 
@@ -71,6 +71,7 @@ def load():
     L.ca_destroy.argtypes = [vp]
     L.ca_last_error.argtypes = [vp]
     L.ca_last_error.restype = C.c_char_p
+    L.ca_set_stream.argtypes = [vp, vp]
     L.ca_set_obstacles.argtypes = [vp, vp, vp, i32]
     L.ca_init_scenario.argtypes = [vp, i32]
     L.ca_set.argtypes = [vp, i32, vp, sz, i32]

@@ -176,13 +176,13 @@ static hipError_t launch_obs(ca_env* e) {
     o.pos_x = e->pos_x; o.pos_y = e->pos_y; o.vel_x = e->vel_x; o.vel_y = e->vel_y;
     o.goal_x = e->goal_x; o.goal_y = e->goal_y; o.nb_count = e->nb_count; o.nb_idx = e->nb_idx;
     o.obst_count = e->obst_count; o.obst_idx = e->obst_idx; o.obst = e->d_obst; o.obs = e->obs;
-    o.A = e->cfg.n_arenas; o.N = e->cfg.n_agents; o.K = e->K > 0 ? e->K : 1; o.S = e->S;
-    if (e->K == 0) o.K = 1;  // nb_idx is allocated with one column; counts are all zero
+    o.A = e->cfg.n_arenas; o.N = e->cfg.n_agents; o.S = e->S;
+    o.K = e->K > 0 ? e->K : 1;  // nb_idx is allocated with one column when K == 0; counts are all zero
+    o.bpa = (o.N + OBS_APB - 1) / OBS_APB;
     memcpy(o.rays, e->rays, sizeof o.rays);
     memcpy(o.oct, e->oct, sizeof o.oct);
-    const size_t total = AN(e);
-    const dim3 grid((unsigned)((total + OBS_APB - 1) / OBS_APB)), block(OBS_BS);
-    hipLaunchKernelGGL(obs_kernel, grid, block, obs_lds_bytes(o.K, o.S), e->stream, o);
+    const dim3 grid((unsigned)((size_t)o.A * o.bpa)), block(OBS_BS);
+    hipLaunchKernelGGL(obs_kernel, grid, block, obs_lds_bytes(o.N), e->stream, o);
     return hipGetLastError();
 }
 
@@ -254,10 +254,6 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         else if (e->K <= 10) r = set_lds_attr_k<10>(e->BS, e->lds);
         else r = set_lds_attr_k<16>(e->BS, e->lds);
     }
-    if (r == hipSuccess && obs_lds_bytes(e->K > 0 ? e->K : 1, e->S) > 48 * 1024)
-        r = hipFuncSetAttribute(reinterpret_cast<const void*>(&obs_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)obs_lds_bytes(e->K > 0 ? e->K : 1, e->S));
     if (r != hipSuccess) {
         fail(nullptr, CA_EHIP, "ca_create: %s", hipGetErrorString(r));
         ca_destroy(e);
@@ -285,6 +281,16 @@ int ca_destroy(ca_env* e) {
     if (e->obs && !e->obs_external) hipFree(e->obs);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
     delete e;
+    return CA_OK;
+}
+
+int ca_set_stream(ca_env* e, void* stream) {
+    if (!e) return CA_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->own_stream && e->stream) HIPCHK(e, hipStreamDestroy(e->stream));
+    e->stream = (hipStream_t)stream;
+    e->own_stream = false;
     return CA_OK;
 }
 
@@ -561,7 +567,7 @@ int ca_launch_info(ca_env* e, int32_t* block, int32_t* grid, int32_t* lds_bytes,
     if (block) *block = e->BS;
     if (grid) *grid = e->grid;
     if (lds_bytes) *lds_bytes = (int32_t)e->lds;
-    if (obs_grid) *obs_grid = (int32_t)((AN(e) + OBS_APB - 1) / OBS_APB);
+    if (obs_grid) *obs_grid = (int32_t)((size_t)e->cfg.n_arenas * ((e->cfg.n_agents + OBS_APB - 1) / OBS_APB));
     return CA_OK;
 }
 

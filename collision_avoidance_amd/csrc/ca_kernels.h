@@ -647,105 +647,194 @@ __global__ void reset_arena_kernel(const StepArgs p) {  // after reset_kernel: p
 
 // ============================================================================================
 // Laser observation (env.py:231-318, utils.py:5-113).
-// 16 lanes per agent = one lane per ray; a wave covers 4 agents.  The 16 lanes first build the
-// agent's segment list (8 octagon chords per ORCA agent neighbour + one segment per ORCA obstacle
-// neighbour), rotated into the goal-aligned frame, in LDS; then every lane casts its ray over
-// all segments (broadcast LDS reads) and writes its 4 floats: 16 lanes x 16 B = the agent's
-// 256-B observation row, so a wave stores 1 KiB contiguously.
+//
+// A workgroup (256 lanes) owns 16 agents of ONE arena; 16 lanes per agent.  The arena's
+// positions/velocities are staged in LDS once (the neighbour gathers then never leave the CU).
+// Phase A -- lane per SEGMENT: the 16 lanes of an agent walk its segment list (8 octagon chords
+//   per ORCA agent neighbour, one segment per ORCA obstacle neighbour), rotate each segment into
+//   the goal-aligned frame and test it only against the rays that can possibly reach it: the
+//   rays inside the segment's angular span as seen from the origin (a conservative superset, see
+//   ray_span).  The ray/segment test itself is the reference's arithmetic, so culling never
+//   changes a result.  A hit is merged into the ray's slot with one LDS ds_min_u64 on the key
+//   (distance bits << 32 | segment index): the minimum distance wins and equal distances resolve
+//   to the first segment, exactly like a serial first-minimum scan.
+// Phase B -- lane per RAY: re-derives the winning segment's hit point and velocity and writes its
+//   4 floats; the 16 lanes of an agent write its 256-B row, a wave stores 1 KiB contiguously.
 // ============================================================================================
 struct ObsArgs {
     const float *pos_x, *pos_y, *vel_x, *vel_y, *goal_x, *goal_y;
     const int *nb_count, *nb_idx, *obst_count, *obst_idx;
     const ObstDev* obst;
     float* obs;
-    int A, N, K, S;
-    float rays[32];  // env.py:321-332
-    float oct[32];   // env.py:335-350
+    int A, N, K, S, bpa;  // bpa = workgroups per arena = ceil(N / 16)
+    float rays[32];       // env.py:321-332
+    float oct[32];        // env.py:335-350
 };
 
 constexpr int OBS_BS = 256;
-constexpr int OBS_APB = OBS_BS / 16;  // agents per block
+constexpr int OBS_APB = OBS_BS / 16;  // agents per workgroup
 
-__host__ __device__ inline size_t obs_lds_bytes(int K, int S) {
-    return (size_t)OBS_APB * ((size_t)(8 * K + S) * 32 + 32);  // +32: stagger against bank conflicts
+// LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | nb idx [16][16] | obstacle idx [16][8]
+__host__ __device__ inline size_t obs_lds_bytes(int N) {
+    return (size_t)N * 16 + OBS_APB * 16 * 8 + OBS_APB * 16 * 4 + OBS_APB * 8 * 4 + 64 * 4;
+}
+
+struct SegGeom {  // one segment in the goal-aligned frame, in the reference's intermediate terms
+    float s02x, s02y;  // utils.py:19-20  p0 - p2, p0 = (0,0)
+    float s32x, s32y;  // utils.py:11-12  p3 - p2
+    float t_numer;     // utils.py:26
+    float r1x, r1y, r2x, r2y;
+};
+
+// position of a point on the "ray dial": ray i points along (cos(i d), -sin(i d)), d = 2pi/16;
+// returns u in [0,16) with |error| < 1e-4.  Only used to pick candidate rays (never for results).
+__device__ __forceinline__ float ray_dial(float x, float y) {
+    const float yy = -y;
+    const float ax = fabsf(x), ay = fabsf(yy);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mn * __builtin_amdgcn_rcpf(mx);
+    const float s = a * a;
+    float r = a * (0.99997726f + s * (-0.33262347f + s * (0.19354346f + s * (-0.11643287f +
+              s * (0.05265332f + s * -0.01172120f)))));
+    r = (ay > ax) ? 1.57079632679f - r : r;
+    r = (x < 0.0f) ? 3.14159265359f - r : r;
+    r = (yy < 0.0f) ? -r : r;
+    const float u = r * 2.54647908947f;  // 16 / (2 pi)
+    return (u < 0.0f) ? u + 16.0f : u;
+}
+
+// Candidate rays [i0, i1] (take & 15) for a segment with end points p2, p3: every ray the exact
+// test could accept lies inside.  The exact test accepts a ray only if its direction is between
+// the directions of p2 and p3 (short way round) up to fp32 rounding of two cross products, i.e.
+// up to ~1e-7 rad unless an end point is very close to the origin compared with the other;
+// the dial error is < 1e-4 and the margin is 0.01 dial units (3.9e-3 rad).  Segments passing
+// (almost) through the origin, where "short way round" is ill-defined, get all 16 rays.
+__device__ __forceinline__ void ray_span(float p2x, float p2y, float p3x, float p3y, int* i0, int* i1) {
+    const float n2 = p2x * p2x + p2y * p2y, n3 = p3x * p3x + p3y * p3y;
+    const float u2 = ray_dial(p2x, p2y), u3 = ray_dial(p3x, p3y);
+    float du = u3 - u2;
+    du = (du > 8.0f) ? du - 16.0f : du;
+    du = (du <= -8.0f) ? du + 16.0f : du;
+    const bool all = (fabsf(du) > 7.8f) || !(fminf(n2, n3) > 1e-6f * fmaxf(n2, n3)) || !(fminf(n2, n3) > 1e-12f);
+    const float lo = u2 + fminf(du, 0.0f) - 0.01f, hi = u2 + fmaxf(du, 0.0f) + 0.01f;
+    *i0 = all ? 0 : (int)ceilf(lo);
+    *i1 = all ? 15 : (int)floorf(hi);
 }
 
 __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     extern __shared__ float4 smem4[];
     const int tid = threadIdx.x;
     const int g = tid >> 4, r = tid & 15;
-    const long long q = (long long)blockIdx.x * OBS_APB + g;
-    const int total = p.A * p.N;
-    const bool active = q < total;
     const int N = p.N, K = p.K, S = p.S;
-    const int mcap = 8 * K + S;
-    float4* seg = smem4 + (size_t)g * (2 * mcap + 2);  // per agent: mcap x (2 float4) + stagger
+    const int a = blockIdx.x / p.bpa;
+    const int i = (blockIdx.x - a * p.bpa) * OBS_APB + g;
+    const bool active = i < N;
+    const size_t q = (size_t)a * N + (active ? i : 0);
 
-    int M = 0;
+    float* s_px = reinterpret_cast<float*>(smem4);
+    float* s_py = s_px + N;
+    float* s_vx = s_py + N;
+    float* s_vy = s_vx + N;
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_vy + N);  // N*16 B: 8-aligned
+    int* s_nb = reinterpret_cast<int*>(s_key + OBS_APB * 16);
+    int* s_ob = s_nb + OBS_APB * 16;
+    float* s_rays = reinterpret_cast<float*>(s_ob + OBS_APB * 8);  // [32] rays then [32] octagon
+    float* s_oct = s_rays + 32;
+    if (tid < 32) { s_rays[tid] = p.rays[tid]; s_oct[tid] = p.oct[tid]; }
+
+    for (int t = tid; t < N; t += OBS_BS) {
+        const size_t qa = (size_t)a * N + t;
+        s_px[t] = p.pos_x[qa]; s_py[t] = p.pos_y[qa]; s_vx[t] = p.vel_x[qa]; s_vy[t] = p.vel_y[qa];
+    }
+    int nn = 0, ns = 0;
+    float gx = 0.0f, gy = 0.0f;
     if (active) {
-        const int a = (int)(q / N), i = (int)(q - (long long)a * N);
-        const int nn = p.nb_count[q], ns = p.obst_count[q];
-        M = 8 * nn + ns;
-        if (M > 0) {
-            const float mx = p.pos_x[q], my = p.pos_y[q];
-            double ox, oy;  // env.py:236: orientation = comp_pref_vel of the current state
-            pref_dir64(mx, my, p.goal_x[q], p.goal_y[q], &ox, &oy);
-            const float c = (float)ox, s = (float)(-oy);  // utils.py:48-51 for a unit vector
-            for (int m = r; m < M; m += 16) {
-                float x1, y1, x2, y2, vx, vy;
-                if (m < 8 * nn) {  // env.py:283-294
-                    const int k = m >> 3, e = m & 7;
-                    const int nb = p.nb_idx[((size_t)a * K + k) * N + i];
-                    const size_t qn = (size_t)a * N + nb;
-                    const float rx = p.pos_x[qn] - mx, ry = p.pos_y[qn] - my;
-                    x1 = p.oct[4 * e] + rx; y1 = p.oct[4 * e + 1] + ry;
-                    x2 = p.oct[4 * e + 2] + rx; y2 = p.oct[4 * e + 3] + ry;
-                    vx = p.vel_x[qn]; vy = p.vel_y[qn];  // env.py:252
-                } else {  // env.py:305-315
-                    const int v1 = p.obst_idx[((size_t)a * S + (m - 8 * nn)) * N + i];
-                    const ObstDev o1 = load_obst(p.obst, v1);
-                    const ObstDev o2 = load_obst(p.obst, o1.next);
-                    x1 = o1.px - mx; y1 = o1.py - my;
-                    x2 = o2.px - mx; y2 = o2.py - my;
-                    vx = 0.0f; vy = 0.0f;
-                }
-                const float lvx = x1 + vx, lvy = y1 + vy;                  // utils.py:57
-                const float r1x = c * x1 - s * y1, r1y = s * x1 + c * y1;  // utils.py:59
-                const float r2x = c * x2 - s * y2, r2y = s * x2 + c * y2;  // utils.py:60
-                const float rvx = c * lvx - s * lvy, rvy = s * lvx + c * lvy;  // utils.py:61
-                const float s32x = r2x - r1x, s32y = r2y - r1y;            // utils.py:11-12
-                const float s02x = 0.0f - r1x, s02y = 0.0f - r1y;          // utils.py:19-20
-                const float t_numer = s32x * s02y - s32y * s02x;           // utils.py:26
-                seg[2 * m] = make_float4(s02x, s02y, s32x, s32y);
-                seg[2 * m + 1] = make_float4(t_numer, rvx - r1x, rvy - r1y, 0.0f);  // utils.py:62
+        nn = p.nb_count[q]; ns = p.obst_count[q];
+        gx = p.goal_x[q]; gy = p.goal_y[q];
+        if (r < nn) s_nb[g * 16 + r] = p.nb_idx[((size_t)a * K + r) * N + i];
+        if (r < ns) s_ob[g * 8 + r] = p.obst_idx[((size_t)a * S + r) * N + i];
+    }
+    s_key[g * 16 + r] = ~0ull;
+    __syncthreads();
+
+    const int M = 8 * nn + ns;
+    float c = 1.0f, s = 0.0f, mx = 0.0f, my = 0.0f;
+    if (M > 0) {
+        mx = s_px[i]; my = s_py[i];
+        double ox, oy;  // env.py:236: orientation = comp_pref_vel of the current state
+        pref_dir64(mx, my, gx, gy, &ox, &oy);
+        c = (float)ox; s = (float)(-oy);  // utils.py:48-51 for a unit vector
+    }
+    // segment m of this agent in the rotated frame (env.py:283-294, 305-315; utils.py:55-62)
+    auto build = [&](int m, SegGeom& sg, float& velx, float& vely, bool want_vel) {
+        float x1, y1, x2, y2, vx = 0.0f, vy = 0.0f;
+        if (m < 8 * nn) {
+            const int k = m >> 3, e = m & 7;
+            const int nb = s_nb[g * 16 + k];
+            const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
+            const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
+            x1 = oc.x + rx; y1 = oc.y + ry;
+            x2 = oc.z + rx; y2 = oc.w + ry;
+            if (want_vel) { vx = s_vx[nb]; vy = s_vy[nb]; }  // env.py:252
+        } else {
+            const ObstDev o1 = load_obst(p.obst, s_ob[g * 8 + (m - 8 * nn)]);
+            const ObstDev o2 = load_obst(p.obst, o1.next);
+            x1 = o1.px - mx; y1 = o1.py - my;
+            x2 = o2.px - mx; y2 = o2.py - my;
+        }
+        sg.r1x = c * x1 - s * y1; sg.r1y = s * x1 + c * y1;  // utils.py:59
+        sg.r2x = c * x2 - s * y2; sg.r2y = s * x2 + c * y2;  // utils.py:60
+        sg.s32x = sg.r2x - sg.r1x; sg.s32y = sg.r2y - sg.r1y;
+        sg.s02x = 0.0f - sg.r1x; sg.s02y = 0.0f - sg.r1y;
+        sg.t_numer = sg.s32x * sg.s02y - sg.s32y * sg.s02x;
+        if (want_vel) {
+            const float lvx = x1 + vx, lvy = y1 + vy;                      // utils.py:57
+            const float rvx = c * lvx - s * lvy, rvy = s * lvx + c * lvy;  // utils.py:61
+            velx = rvx - sg.r1x; vely = rvy - sg.r1y;                      // utils.py:62
+        }
+    };
+    // utils.py:5-40 for the ray with end point (s10x, s10y) starting at the origin
+    auto hit = [&](const SegGeom& sg, float s10x, float s10y, float& d, float& hx, float& hy) -> bool {
+        const float denom = s10x * sg.s32y - sg.s32x * s10y;          // utils.py:14
+        if (denom == 0.0f) return false;
+        const bool dpos = denom > 0.0f;
+        const float s_numer = s10x * sg.s02y - s10y * sg.s02x;        // utils.py:21
+        if ((s_numer < 0.0f) == dpos) return false;
+        if ((sg.t_numer < 0.0f) == dpos) return false;
+        if (((s_numer > denom) == dpos) || ((sg.t_numer > denom) == dpos)) return false;
+        const float t = sg.t_numer / denom;                            // utils.py:34
+        hx = 0.0f + t * s10x; hy = 0.0f + t * s10y;                    // utils.py:36-37
+        d = sqrtf(hx * hx + hy * hy);                                  // utils.py:38
+        return true;
+    };
+
+    // ---- phase A: lane per segment ----
+    for (int m = r; m < M; m += 16) {
+        SegGeom sg;
+        float dum0, dum1;
+        build(m, sg, dum0, dum1, false);
+        int i0, i1;
+        ray_span(sg.r1x, sg.r1y, sg.r2x, sg.r2y, &i0, &i1);
+        for (int ii = i0; ii <= i1; ++ii) {
+            const int ray = ii & 15;
+            float d, hx, hy;
+            if (hit(sg, s_rays[2 * ray] - 0.0f, s_rays[2 * ray + 1] - 0.0f, d, hx, hy)) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)m;
+                atomicMin(&s_key[g * 16 + ray], key);
             }
         }
     }
     __syncthreads();
     if (!active) return;
-    const float INF = __int_as_float(0x7f800000);
-    const float s10x = p.rays[2 * r] - 0.0f, s10y = p.rays[2 * r + 1] - 0.0f;  // utils.py:9-10
-    float best = INF, bx = 0.0f, by = 0.0f;
-    int bi = -1;
-    for (int m = 0; m < M; ++m) {
-        const float4 A0 = seg[2 * m];
-        const float denom = s10x * A0.w - A0.z * s10y;                 // utils.py:14
-        if (denom == 0.0f) continue;
-        const bool dpos = denom > 0.0f;
-        const float s_numer = s10x * A0.y - s10y * A0.x;               // utils.py:21
-        if ((s_numer < 0.0f) == dpos) continue;
-        const float t_numer = seg[2 * m + 1].x;
-        if ((t_numer < 0.0f) == dpos) continue;
-        if (((s_numer > denom) == dpos) || ((t_numer > denom) == dpos)) continue;
-        const float t = t_numer / denom;                               // utils.py:34
-        const float hx = 0.0f + t * s10x, hy = 0.0f + t * s10y;        // utils.py:36-37
-        const float d = sqrtf(hx * hx + hy * hy);                      // utils.py:38
-        if (d < best) { best = d; bx = hx; by = hy; bi = m; }          // first minimum wins
-    }
-    float vx = 0.0f, vy = 0.0f;
-    if (bi >= 0 && !(bx == 0.0f && by == 0.0f)) {                      // utils.py:103
-        const float4 B = seg[2 * bi + 1];
-        vx = B.y; vy = B.z;
+    // ---- phase B: lane per ray ----
+    const unsigned long long key = s_key[g * 16 + r];
+    float bx = 0.0f, by = 0.0f, vx = 0.0f, vy = 0.0f;
+    if (key != ~0ull) {
+        SegGeom sg;
+        float wx, wy, d;
+        build((int)(unsigned)key, sg, wx, wy, true);
+        hit(sg, s_rays[2 * r] - 0.0f, s_rays[2 * r + 1] - 0.0f, d, bx, by);
+        if (!(bx == 0.0f && by == 0.0f)) { vx = wx; vy = wy; }  // utils.py:103
     }
     reinterpret_cast<float4*>(p.obs)[q * 16 + r] = make_float4(bx, by, vx, vy);
 }

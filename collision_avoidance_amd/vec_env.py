@@ -55,14 +55,15 @@ class VecCollisionAvoidanceEnv:
         self.K, self.S = self.cfg.max_neighbors, self.cfg.max_obst_neighbors
         self.device = int(device)
         self.use_torch = (torch is not None and torch.cuda.is_available()) if use_torch is None else bool(use_torch)
-        stream = None
-        if self.use_torch:
-            torch.cuda.set_device(self.device)
-            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         h = C.c_void_p()
-        rc = self.L.ca_create(C.byref(self.cfg), self.device, stream, C.byref(h))
+        rc = self.L.ca_create(C.byref(self.cfg), self.device, None, C.byref(h))
         _lib.check(self.L, None, rc, "ca_create")
         self.h = h
+        if self.use_torch:
+            # run on PyTorch's current stream (its handle is 0 for the default stream), so that
+            # tensor ops and torch.cuda.Event order naturally with the environment's kernels
+            torch.cuda.set_device(self.device)
+            self._call("ca_set_stream", self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         self._obs_t = None
         if self.use_torch:
             dev = torch.device("cuda", self.device)

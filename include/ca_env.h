@@ -119,6 +119,9 @@ typedef struct ca_env ca_env;
 int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out);
 int ca_destroy(ca_env* env);
 const char* ca_last_error(const ca_env* env);
+/* Run on the caller's stream from now on (hipStream_t; NULL = the device's default stream).
+ * The previous stream is drained first. */
+int ca_set_stream(ca_env* env, void* stream);
 
 /* Replaces sim.addObstacle + sim.processObstacles (env.py:118-123, 143-149): the same polygons
  * for every arena.  verts_xy: host array [sum(poly_sizes), 2]. */

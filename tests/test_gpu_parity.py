@@ -96,6 +96,47 @@ def test_orca_rollout_bit_exact(name, A, N, scenario, over, steps, every):
     gpu.close()
 
 
+def test_obs_adversarial_geometry():
+    """The observation kernel culls rays by the angular span of each segment; the culling must be a
+    superset of what the exact test accepts.  Neighbours are placed exactly on ray directions, on
+    the octagon's in/circum-radius, inside the octagon and almost on top of the agent."""
+    from collision_avoidance_amd import _lib
+    N, dists = 4, [1e-4, 0.03, 0.25, 0.46193975, 0.4619398, 0.5, 0.50000006, 0.7, 1.0, 1.4999, 2.0]
+    cases = []
+    for k in range(32):                      # direction: every ray and every half-ray
+        for d in dists:
+            ang = -k * (2 * np.pi / 32)
+            cases.append((d * np.cos(ang), d * np.sin(ang)))
+    rng = np.random.RandomState(3)
+    A = len(cases)
+    p = H.scenario_params("crowd", N, neighbor_dist=3.0, max_neighbors=3)
+    polys = [[(-50.0, -0.2), (50.0, -0.2)]]  # a 2-vertex wall just below: passes close to the origin
+    gpu = H.make_gpu(A, N, "crowd", p, seed=2, polys=polys)
+    orc = H.make_oracle(A, N, "crowd", p, seed=2, polys=polys)
+    px = np.zeros((A, N), np.float32); py = np.zeros((A, N), np.float32)
+    for a, (dx, dy) in enumerate(cases):
+        px[a] = [10.0, 10.0 + dx, 10.0 - 2 * dx + 0.9, 10.0 + 1.3]
+        py[a] = [0.0, dy, -2 * dy + 0.3, 1.1]
+    gxy = rng.uniform(-20, 20, (2, A, N)).astype(np.float32)
+    gxy[0, ::3] = px[::3] + 5.0; gxy[1, ::3] = py[::3]      # goal straight along +x: frame unrotated
+    vel = rng.uniform(-0.7, 0.7, (2, A, N)).astype(np.float32)
+    for env, F in ((gpu, _lib), (orc, o)):
+        env.set(F.FLD_POS_X, px); env.set(F.FLD_POS_Y, py)
+        env.set(F.FLD_VEL_X, vel[0]); env.set(F.FLD_VEL_Y, vel[1])
+        env.set(F.FLD_GOAL_X, gxy[0]); env.set(F.FLD_GOAL_Y, gxy[1])
+    for s in range(3):
+        gpu.orca_step(with_obs=True, no_done=True)
+        orc.orca_step(flags=o.F_OBS | o.F_NODONE)
+        H.assert_state_equal(gpu, orc, "adversarial step %d" % s, obs=True)
+        # put the agents back so that every step probes the crafted geometry: reset = new positions
+        # + observation from the neighbour lists of the last step (env.py:461-488)
+        gpu.reset(px, py)
+        orc.reset(px, py, flags=o.F_OBS)
+        H.assert_state_equal(gpu, orc, "adversarial reset %d" % s, obs=True)
+    assert np.abs(gpu.get(_lib.FLD_OBS)).max() > 0
+    gpu.close()
+
+
 def test_regoal_and_rollout_call():
     N = 16
     p = scenarios.bench_params(N, 1.5, 5)
