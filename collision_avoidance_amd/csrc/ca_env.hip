@@ -31,6 +31,7 @@ struct ca_env {
     unsigned long long* arena_stats = nullptr;
     float* obs = nullptr;
     bool obs_external = false;
+    unsigned long long* dbg = nullptr;  // CA_STAMPS diagnostic build only
     float *tmp_x = nullptr, *tmp_y = nullptr;  // staging for explicit reset positions / host actions
     ObstDev* d_obst = nullptr;
     std::vector<ObstDev> h_obst;
@@ -126,7 +127,7 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.nb_count = e->nb_count; a.nb_idx = e->nb_idx; a.obst_count = e->obst_count; a.obst_idx = e->obst_idx;
     a.step_count = e->step_count; a.arena_done = e->arena_done; a.episode = e->episode;
     a.arena_stats = e->arena_stats; a.obst = e->d_obst; a.actions = actions;
-    a.reset_px = nullptr; a.reset_py = nullptr;
+    a.reset_px = nullptr; a.reset_py = nullptr; a.dbg = e->dbg;
     a.reward_scale = c.reward_scale; a.seed = c.seed; a.arena_offset = c.arena_offset;
     a.n_obst = (int)e->h_obst.size(); a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
     a.K = e->K; a.S = e->S; a.flags = flags;
@@ -249,6 +250,9 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     if (r == hipSuccess) r = dalloc(&e->arena_stats, A * ST_STRIDE);
     if (r == hipSuccess) r = dalloc(&e->obs, an * CA_OBS_DIM);
     if (r == hipSuccess) r = dalloc(&e->d_obst, (size_t)1);
+#ifdef CA_STAMPS
+    if (r == hipSuccess) r = dalloc(&e->dbg, (size_t)e->grid * (e->BS / 64) * 16);
+#endif
     if (r == hipSuccess && e->lds > 48 * 1024) {
         if (e->K <= 5) r = set_lds_attr_k<5>(e->BS, e->lds);
         else if (e->K <= 10) r = set_lds_attr_k<10>(e->BS, e->lds);
@@ -276,7 +280,7 @@ int ca_destroy(ca_env* e) {
     void* bufs[] = {e->pos_x, e->pos_y, e->vel_x, e->vel_y, e->pref_x, e->pref_y, e->goal_x, e->goal_y,
                     e->goal2_x, e->goal2_y, e->reward, e->tmp_x, e->tmp_y, e->agent_done, e->arrive_step,
                     e->regoal_count, e->nb_count, e->nb_idx, e->obst_count, e->obst_idx, e->step_count,
-                    e->arena_done, e->episode, e->arena_stats, e->d_obst};
+                    e->arena_done, e->episode, e->arena_stats, e->d_obst, e->dbg};
     for (void* b : bufs) if (b) hipFree(b);
     if (e->obs && !e->obs_external) hipFree(e->obs);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -309,11 +313,18 @@ int ca_set_obstacles(ca_env* e, const float* verts_xy, const int32_t* poly_sizes
             const V2 pp = mk(verts_xy[2 * (off + ip)], verts_xy[2 * (off + ip) + 1]);
             const V2 u = normalize(pn - pt);
             ObstDev o;
+            memset(&o, 0, sizeof o);
             o.px = pt.x; o.py = pt.y; o.ux = u.x; o.uy = u.y;
             o.next = base + in; o.prev = base + ip;
             o.convex = (n == 2) ? 1 : (leftOf(pp, pt, pn) >= 0.0f ? 1 : 0);
-            o.pad = 0;
             tab.push_back(o);
+        }
+        for (int i = 0; i < n; ++i) {  // denormalise: each edge record also carries its two neighbours
+            ObstDev& o = tab[base + i];
+            const ObstDev& nx = tab[o.next];
+            const ObstDev& pv = tab[o.prev];
+            o.qx = nx.px; o.qy = nx.py; o.qux = nx.ux; o.quy = nx.uy; o.qconvex = nx.convex;
+            o.pux = pv.ux; o.puy = pv.uy;
         }
         off += n;
     }
@@ -559,6 +570,19 @@ int ca_debug_math(ca_env* e, int32_t op, const void* in, void* out, int32_t n) {
     HIPCHK(e, hipMemcpy(out, dout, out_b[op] * n, hipMemcpyDeviceToHost));
     hipFree(di);
     hipFree(dout);
+    return CA_OK;
+}
+
+/* CA_STAMPS diagnostic build only (not declared in include/ca_env.h): per-wave phase time stamps
+ * of the last step kernel, [waves][16] u64. */
+int ca_debug_stamps(ca_env* e, unsigned long long* out, int32_t max_waves, int32_t* n_waves) {
+    if (!e || !e->dbg) return fail(e, CA_EINVAL, "ca_debug_stamps: not a CA_STAMPS build");
+    const int nw = e->grid * (e->BS / 64);
+    if (n_waves) *n_waves = nw;
+    const int n = nw < max_waves ? nw : max_waves;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(out, e->dbg, (size_t)n * 16 * 8, hipMemcpyDeviceToHost));
     return CA_OK;
 }
 

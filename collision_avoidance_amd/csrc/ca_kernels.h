@@ -18,10 +18,15 @@ namespace ca {
 constexpr int SMAX = 8;       // CA_MAX_OBST_NEIGHBORS
 constexpr float EPS = 0.00001f;
 
-struct ObstDev {  // one obstacle vertex; the edge is (this, next)
-    float px, py, ux, uy;
-    int next, prev, convex, pad;
+struct ObstDev {  // one obstacle edge (this vertex -> next vertex) with everything ORCA needs about
+                  // its two end vertices, so that no dependent `next`/`prev` gathers are required
+    float px, py, ux, uy;    // this vertex, unit direction of this edge
+    float qx, qy, qux, quy;  // next vertex, unit direction of the edge leaving it
+    float pux, puy;          // unit direction of the edge arriving at this vertex (prev's unitDir)
+    int next, prev;
+    int convex, qconvex, pad0, pad1;
 };
+static_assert(sizeof(ObstDev) == 64, "edge record is one 64-byte line");
 
 struct Line {
     V2 point, dir;
@@ -39,6 +44,7 @@ struct StepArgs {
     const float* actions;  // null: orca_step
     const float* reset_px; // explicit reset positions (reset kernel only)
     const float* reset_py;
+    unsigned long long* dbg;  // CA_STAMPS diagnostic build only: [waves][16] phase cycle counts
     double reward_scale;
     uint64_t seed;
     int64_t arena_offset;
@@ -80,8 +86,11 @@ __device__ __forceinline__ bool lp1(const LS& ls, int lineNo, float radius, V2 o
     const float sq = sqrtf(disc);
     float tLeft = -dp - sq;
     float tRight = -dp + sq;
+    Line Mn = L;
+    if (lineNo > 0) Mn = ls.get(0);
     for (int j = 0; j < lineNo; ++j) {
-        const Line M = ls.get(j);
+        const Line M = Mn;
+        if (j + 1 < lineNo) Mn = ls.get(j + 1);  // next line is in flight while this one is used
         const float den = det(L.dir, M.dir);
         const float num = det(M.dir, L.point - M.point);
         if (fabsf(den) <= EPS) {
@@ -195,22 +204,28 @@ __device__ __forceinline__ Line agent_orca_line(V2 pos, V2 vel, V2 opos, V2 ovel
 
 __device__ __forceinline__ ObstDev load_obst(const ObstDev* __restrict__ t, int i) {
     const int4* q = reinterpret_cast<const int4*>(t + i);
-    const int4 a = q[0], b = q[1];
+    const int4 a = q[0], b = q[1], c = q[2], d = q[3];
     ObstDev o;
     o.px = __int_as_float(a.x); o.py = __int_as_float(a.y); o.ux = __int_as_float(a.z); o.uy = __int_as_float(a.w);
-    o.next = b.x; o.prev = b.y; o.convex = b.z; o.pad = 0;
+    o.qx = __int_as_float(b.x); o.qy = __int_as_float(b.y); o.qux = __int_as_float(b.z); o.quy = __int_as_float(b.w);
+    o.pux = __int_as_float(c.x); o.puy = __int_as_float(c.y); o.next = c.z; o.prev = c.w;
+    o.convex = d.x; o.qconvex = d.y; o.pad0 = 0; o.pad1 = 0;
     return o;
 }
 
-// App. A.3: the half-plane induced by the obstacle edge starting at vertex i1.  Returns false
-// when the edge yields no line (already covered, non-convex vertex, foreign leg).
-__device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, int i1, V2 pos, V2 vel, float R,
+// App. A.3: the half-plane induced by the obstacle edge e.  Returns false when the edge yields no
+// line (already covered, non-convex vertex, foreign leg).  "o1"/"o2" are the edge's two vertices;
+// the oblique cases collapse the edge onto one of them, exactly as the contract's o2<-o1 / o1<-o2.
+__device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, int e, V2 pos, V2 vel, float R,
                                                float invTO, const LdsLines& ls, int nl, Line& line) {
-    ObstDev o1 = load_obst(tab, i1);
-    int i2 = o1.next;
-    ObstDev o2 = load_obst(tab, i2);
-    const V2 rp1 = mk(o1.px, o1.py) - pos;
-    const V2 rp2 = mk(o2.px, o2.py) - pos;
+    const ObstDev E = load_obst(tab, e);
+    V2 o1p = mk(E.px, E.py), o2p = mk(E.qx, E.qy);
+    V2 o1u = mk(E.ux, E.uy), o2u = mk(E.qux, E.quy);
+    V2 lnu = mk(E.pux, E.puy);  // unitDir of o1's left neighbour (its prev vertex)
+    bool o1c = E.convex != 0, o2c = E.qconvex != 0;
+    bool same = false;
+    const V2 rp1 = o1p - pos;
+    const V2 rp2 = o2p - pos;
     for (int j = 0; j < nl; ++j) {
         const Line M = ls.get(j);
         if (det(invTO * rp1 - M.point, M.dir) - invTO * R >= -EPS &&
@@ -218,18 +233,18 @@ __device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, 
             return false;
     }
     const float distSq1 = absSq(rp1), distSq2 = absSq(rp2), radiusSq = sqr(R);
-    const V2 ov = mk(o2.px, o2.py) - mk(o1.px, o1.py);
+    const V2 ov = o2p - o1p;
     const float s = dot(-rp1, ov) / absSq(ov);
     const float distSqLine = absSq(-rp1 - s * ov);
     if (s < 0.0f && distSq1 <= radiusSq) {
-        if (o1.convex) {
+        if (o1c) {
             line.point = mk(0.0f, 0.0f);
             line.dir = normalize(mk(-rp1.y, rp1.x));
             return true;
         }
         return false;
     } else if (s > 1.0f && distSq2 <= radiusSq) {
-        if (o2.convex && det(rp2, mk(o2.ux, o2.uy)) >= 0.0f) {
+        if (o2c && det(rp2, o2u) >= 0.0f) {
             line.point = mk(0.0f, 0.0f);
             line.dir = normalize(mk(-rp2.y, rp2.x));
             return true;
@@ -237,50 +252,49 @@ __device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, 
         return false;
     } else if (s >= 0.0f && s < 1.0f && distSqLine <= radiusSq) {
         line.point = mk(0.0f, 0.0f);
-        line.dir = -mk(o1.ux, o1.uy);
+        line.dir = -o1u;
         return true;
     }
     V2 leftLeg, rightLeg;
     if (s < 0.0f && distSqLine <= radiusSq) {
-        if (!o1.convex) return false;
-        o2 = o1; i2 = i1;
+        if (!o1c) return false;
+        o2p = o1p; o2u = o1u; o2c = o1c; same = true;  // o2 <- o1
         const float leg1 = sqrtf(distSq1 - radiusSq);
         leftLeg = vdiv(mk(rp1.x * leg1 - rp1.y * R, rp1.x * R + rp1.y * leg1), distSq1);
         rightLeg = vdiv(mk(rp1.x * leg1 + rp1.y * R, -rp1.x * R + rp1.y * leg1), distSq1);
     } else if (s > 1.0f && distSqLine <= radiusSq) {
-        if (!o2.convex) return false;
-        o1 = o2; i1 = i2;
+        if (!o2c) return false;
+        lnu = o1u;                                     // the new o1's prev vertex is the old o1
+        o1p = o2p; o1u = o2u; o1c = o2c; same = true;  // o1 <- o2
         const float leg2 = sqrtf(distSq2 - radiusSq);
         leftLeg = vdiv(mk(rp2.x * leg2 - rp2.y * R, rp2.x * R + rp2.y * leg2), distSq2);
         rightLeg = vdiv(mk(rp2.x * leg2 + rp2.y * R, -rp2.x * R + rp2.y * leg2), distSq2);
     } else {
-        if (o1.convex) {
+        if (o1c) {
             const float leg1 = sqrtf(distSq1 - radiusSq);
             leftLeg = vdiv(mk(rp1.x * leg1 - rp1.y * R, rp1.x * R + rp1.y * leg1), distSq1);
         } else {
-            leftLeg = -mk(o1.ux, o1.uy);
+            leftLeg = -o1u;
         }
-        if (o2.convex) {
+        if (o2c) {
             const float leg2 = sqrtf(distSq2 - radiusSq);
             rightLeg = vdiv(mk(rp2.x * leg2 + rp2.y * R, -rp2.x * R + rp2.y * leg2), distSq2);
         } else {
-            rightLeg = mk(o1.ux, o1.uy);
+            rightLeg = o1u;
         }
     }
-    const ObstDev ln = load_obst(tab, o1.prev);
     bool leftForeign = false, rightForeign = false;
-    if (o1.convex && det(leftLeg, -mk(ln.ux, ln.uy)) >= 0.0f) {
-        leftLeg = -mk(ln.ux, ln.uy);
+    if (o1c && det(leftLeg, -lnu) >= 0.0f) {
+        leftLeg = -lnu;
         leftForeign = true;
     }
-    if (o2.convex && det(rightLeg, mk(o2.ux, o2.uy)) <= 0.0f) {
-        rightLeg = mk(o2.ux, o2.uy);
+    if (o2c && det(rightLeg, o2u) <= 0.0f) {
+        rightLeg = o2u;
         rightForeign = true;
     }
-    const V2 leftCut = invTO * (mk(o1.px, o1.py) - pos);
-    const V2 rightCut = invTO * (mk(o2.px, o2.py) - pos);
+    const V2 leftCut = invTO * (o1p - pos);
+    const V2 rightCut = invTO * (o2p - pos);
     const V2 cutVec = rightCut - leftCut;
-    const bool same = (i1 == i2);
     const float t = same ? 0.5f : dot(vel - leftCut, cutVec) / absSq(cutVec);
     const float tLeft = dot(vel - leftCut, leftLeg);
     const float tRight = dot(vel - rightCut, rightLeg);
@@ -300,7 +314,7 @@ __device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, 
     const float dLeft = (tLeft < 0.0f) ? INF : absSq(vel - (leftCut + tLeft * leftLeg));
     const float dRight = (tRight < 0.0f) ? INF : absSq(vel - (rightCut + tRight * rightLeg));
     if (dCut <= dLeft && dCut <= dRight) {
-        line.dir = -mk(o1.ux, o1.uy);
+        line.dir = -o1u;
         line.point = leftCut + R * invTO * mk(-line.dir.y, line.dir.x);
         return true;
     } else if (dLeft <= dRight) {
@@ -315,21 +329,25 @@ __device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, 
     return true;
 }
 
-// sorted insertion into a register-resident list: keeps the `cap` smallest keys ascending; a new
-// key goes behind every key <= it (strict <), displaced entries move down, the last falls off
+// Sorted insertion into a register-resident list kept ascending; a new key goes behind every key
+// <= it and the last entry falls off.  Candidates arrive in increasing index order, so "behind
+// equal keys" is the (distance, index) order of the contract.  Every slot is computed from the OLD
+// list alone -- new[k] = old[k] if old[k] <= x, else x if old[k-1] <= x, else old[k-1] -- so the
+// slots are independent instructions (no carry chain).  A list shorter than the array is stored
+// RIGHT-ALIGNED behind dummy -inf slots (which never move): its largest key is then always the
+// last element, a compile-time index, and the array never has to live in scratch memory.
 template <int MAXN>
-__device__ __forceinline__ void sorted_insert(float (&d)[MAXN], int (&idx)[MAXN], int cap, float nd, int ni) {
-    bool ins = false;
+__device__ __forceinline__ void sorted_insert(float (&d)[MAXN], int (&idx)[MAXN], float x, int xi) {
+    float od[MAXN]; int oi[MAXN]; bool le[MAXN];
+#pragma unroll
+    for (int k = 0; k < MAXN; ++k) { od[k] = d[k]; oi[k] = idx[k]; le[k] = od[k] <= x; }
 #pragma unroll
     for (int k = 0; k < MAXN; ++k) {
-        const bool sw = (k < cap) && (ins || nd < d[k]);
-        const float td = d[k];
-        const int ti = idx[k];
-        d[k] = sw ? nd : td;
-        idx[k] = sw ? ni : ti;
-        nd = sw ? td : nd;
-        ni = sw ? ti : ni;
-        ins = sw;
+        const bool ple = (k == 0) ? true : le[k - 1];
+        const float sd = (k == 0) ? x : od[k - 1];
+        const int si = (k == 0) ? xi : oi[k - 1];
+        d[k] = le[k] ? od[k] : (ple ? x : sd);
+        idx[k] = le[k] ? oi[k] : (ple ? xi : si);
     }
 }
 template <int MAXN>
@@ -339,14 +357,6 @@ __device__ __forceinline__ int pick(const int (&v)[MAXN], int k) {
     for (int j = 1; j < MAXN; ++j) r = (k == j) ? v[j] : r;
     return r;
 }
-template <int MAXN>
-__device__ __forceinline__ float pickf(const float (&v)[MAXN], int k) {
-    float r = v[0];
-#pragma unroll
-    for (int j = 1; j < MAXN; ++j) r = (k == j) ? v[j] : r;
-    return r;
-}
-
 // LDS carve-up of the step kernel (bytes): lines | px py vx vy | misc ints
 __host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S) {
     return (size_t)BS * ((size_t)(K + S) * 16 + 16 + 16);
@@ -357,6 +367,20 @@ __host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S) {
 // actions != null : env.py:367-416 `step`;  actions == null : `orca_step` (env.py:447-450,
 // ALAN:631-636) followed by the done test of ALAN:118-121 unless CA_F_NODONE.
 // ============================================================================================
+#ifdef CA_STAMPS  // diagnostic build: per-wave cycle count of each phase (never in the product library)
+#define CA_STAMP(k)                                                                      \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();                      \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                              \
+        if ((threadIdx.x & 63) == 0 && p.dbg)                                            \
+            p.dbg[((size_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6)) * 16 + (k)] = _t; \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define CA_STAMP(k) do { } while (0)
+#endif
+
 template <int KMAX, int BS>
 __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     extern __shared__ float4 smem4[];
@@ -379,6 +403,7 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     int* s_misc = reinterpret_cast<int*>(s_vy + BS);            // [BS][4]
     LdsLines ls; ls.base = s_lines + tid; ls.stride = BS;
 
+    CA_STAMP(0);
     // ---- load own state (coalesced SoA) ----
     V2 pos = mk(0.0f, 0.0f), vel = mk(0.0f, 0.0f), pref = mk(0.0f, 0.0f);
     float gx = 0.0f, gy = 0.0f;
@@ -403,35 +428,38 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     s_px[tid] = pos.x; s_py[tid] = pos.y; s_vx[tid] = vel.x; s_vy[tid] = vel.y;
     __syncthreads();
 
+    CA_STAMP(1);
     const float INF = __int_as_float(0x7f800000);
     // ---- obstacle neighbours (App. A.2): brute force over the edge table ----
+    const int sofs = SMAX - S;  // the S-entry list is right-aligned in the register array
     float od[SMAX]; int oi[SMAX];
 #pragma unroll
-    for (int k = 0; k < SMAX; ++k) { od[k] = INF; oi[k] = -1; }
+    for (int k = 0; k < SMAX; ++k) { od[k] = (k < sofs) ? -INF : INF; oi[k] = -1; }
     int oin = 0;
     {
         const float rangeSq = sqr(p.time_horizon_obst * p.max_speed + p.radius);
         for (int e = 0; e < p.n_obst; ++e) {
             const ObstDev o1 = p.obst[e];
-            const ObstDev o2 = p.obst[o1.next];
-            const V2 a1 = mk(o1.px, o1.py), a2 = mk(o2.px, o2.py);
+            const V2 a1 = mk(o1.px, o1.py), a2 = mk(o1.qx, o1.qy);
             const float alol = leftOf(a1, a2, pos);
             const float dsl = sqr(alol) / absSq(a2 - a1);
             if (active && dsl < rangeSq && alol < 0.0f) {
                 const float dsq = distSqPointSegment(a1, a2, pos);
                 if (dsq < rangeSq) {
                     ++oin;
-                    sorted_insert<SMAX>(od, oi, S, dsq, e);
+                    sorted_insert<SMAX>(od, oi, dsq, e);
                 }
             }
         }
     }
     const int ocnt = oin < S ? oin : S;
 
+    CA_STAMP(2);
     // ---- agent neighbours (App. A.2): K nearest within neighbor_dist, ties -> lower index ----
+    const int kofs = KMAX - K;  // the K-entry list is right-aligned in the register array
     float nd[KMAX]; int ni[KMAX];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) { nd[k] = INF; ni[k] = -1; }
+    for (int k = 0; k < KMAX; ++k) { nd[k] = (k < kofs) ? -INF : INF; ni[k] = -1; }
     int ncnt = 0;
     if (K > 0) {
         float rangeSq = sqr(p.neighbor_dist);
@@ -439,13 +467,14 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
             const V2 o = mk(s_px[lbase + j], s_py[lbase + j]);
             const float dsq = absSq(pos - o);
             if (active && j != i && dsq < rangeSq) {
-                sorted_insert<KMAX>(nd, ni, K, dsq, j);
+                sorted_insert<KMAX>(nd, ni, dsq, j);
                 if (ncnt < K) ++ncnt;
-                if (ncnt == K) rangeSq = (K == KMAX) ? nd[KMAX - 1] : pickf<KMAX>(nd, K - 1);
+                if (ncnt == K) rangeSq = nd[KMAX - 1];
             }
         }
     }
 
+    CA_STAMP(3);
     // ---- ORCA lines -> LDS table ----
     int nl = 0;
     const float R = p.radius;
@@ -454,7 +483,7 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
         for (int s = 0; s < S; ++s) {
             if (s < ocnt) {
                 Line line;
-                if (obst_orca_line(p.obst, pick<SMAX>(oi, s), pos, vel, R, invTO, ls, nl, line)) {
+                if (obst_orca_line(p.obst, pick<SMAX>(oi, sofs + s), pos, vel, R, invTO, ls, nl, line)) {
                     ls.put(nl, line);
                     ++nl;
                 }
@@ -462,12 +491,13 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
         }
     }
     const int numObstLines = nl;
+    CA_STAMP(4);
     {
         const float invT = 1.0f / p.time_horizon;
         const float invDt = 1.0f / p.time_step;
         for (int k = 0; k < K; ++k) {
             if (k < ncnt) {
-                const int j = lbase + pick<KMAX>(ni, k);
+                const int j = lbase + pick<KMAX>(ni, kofs + k);
                 const Line line = agent_orca_line(pos, vel, mk(s_px[j], s_py[j]), mk(s_vx[j], s_vy[j]), R, invT, invDt);
                 ls.put(nl, line);
                 ++nl;
@@ -475,15 +505,19 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
         }
     }
 
+    CA_STAMP(5);
     // ---- 2-D linear program (App. A.5) ----
     V2 nv = mk(0.0f, 0.0f);
+    int fail = nl;
+    if (active) fail = lp2(ls, nl, p.max_speed, pref, false, nv);
+    CA_STAMP(6);
     if (active) {
-        const int fail = lp2(ls, nl, p.max_speed, pref, false, nv);
         if (fail < nl) lp3<KMAX + SMAX>(ls, nl, numObstLines, fail, p.max_speed, nv);
         // ---- integrate (App. A.1) ----
         vel = nv;
         pos = pos + vel * p.time_step;
     }
+    CA_STAMP(7);
 
     __syncthreads();  // every lane is done with the pre-step arena image
     s_px[tid] = pos.x; s_py[tid] = pos.y;
@@ -501,14 +535,14 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
             bool wall = false;
             for (int e = 0; e < p.n_obst; ++e) {
                 const ObstDev o1 = p.obst[e];
-                const ObstDev o2 = p.obst[o1.next];
-                if (distSqPointSegment(mk(o1.px, o1.py), mk(o2.px, o2.py), pos) < sqr(R)) wall = true;
+                if (distSqPointSegment(mk(o1.px, o1.py), mk(o1.qx, o1.qy), pos) < sqr(R)) wall = true;
             }
             if (pairs) atomicAdd(&red[1], pairs);
             if (wall) atomicAdd(&red[2], 1);
         }
     }
 
+    CA_STAMP(8);
     // ---- reward (env.py:389-400) or preferred velocity towards the goal (env.py:449) ----
     float rew = 0.0f;
     if (active) {
@@ -525,6 +559,7 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
         }
     }
 
+    CA_STAMP(9);
     // ---- step counter and done test (env.py:352-365, 404-410; ALAN:118-121, 547-566) ----
     const bool nodone = (p.flags & 8u) != 0;  // CA_F_NODONE
     int steps = active ? p.step_count[a] : 0;
@@ -588,6 +623,7 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
         if (active && (i & 63) == 0)
             atomicAdd(reinterpret_cast<double*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_SUMREW]), r);
     }
+    CA_STAMP(10);
     __syncthreads();  // all lanes have read red[] and episode[]
     if (active) {
         p.pos_x[q] = pos.x; p.pos_y[q] = pos.y;
@@ -597,10 +633,10 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
         p.obst_count[q] = ocnt;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-            if (k < K) p.nb_idx[((size_t)a * K + k) * N + i] = ni[k];
+            if (k >= kofs) p.nb_idx[((size_t)a * K + (k - kofs)) * N + i] = ni[k];
 #pragma unroll
         for (int k = 0; k < SMAX; ++k)
-            if (k < S) p.obst_idx[((size_t)a * S + k) * N + i] = oi[k];
+            if (k >= sofs) p.obst_idx[((size_t)a * S + (k - sofs)) * N + i] = oi[k];
         if (i == 0) {
             unsigned long long* st = p.arena_stats + (size_t)a * ST_STRIDE;
             if (red[1]) st[ST_COLL] += (unsigned)red[1];
@@ -612,6 +648,7 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
             if (do_reset) p.episode[a] = epi + 1;
         }
     }
+    CA_STAMP(11);
 }
 
 // ============================================================================================
@@ -778,9 +815,8 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             if (want_vel) { vx = s_vx[nb]; vy = s_vy[nb]; }  // env.py:252
         } else {
             const ObstDev o1 = load_obst(p.obst, s_ob[g * 8 + (m - 8 * nn)]);
-            const ObstDev o2 = load_obst(p.obst, o1.next);
             x1 = o1.px - mx; y1 = o1.py - my;
-            x2 = o2.px - mx; y2 = o2.py - my;
+            x2 = o1.qx - mx; y2 = o1.qy - my;
         }
         sg.r1x = c * x1 - s * y1; sg.r1y = s * x1 + c * y1;  // utils.py:59
         sg.r2x = c * x2 - s * y2; sg.r2y = s * x2 + c * y2;  // utils.py:60
