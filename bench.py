@@ -105,27 +105,28 @@ def main():
     pool = (torch.rand((16, A, N), device="cuda", generator=gen) - 0.5)  # actions in [-0.5, 0.5] rad
     full = args.mode == "step"
 
-    def one_step(i, evs=None):
+    nev = 3 if full else 2
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(nev)] for _ in range(args.steps)]
+
+    def one_step(i, ev=None):
+        # the two launches of a full step, each bracketed by HIP events on the stream they run on
+        # (the handle runs on PyTorch's current stream)
+        if ev:
+            ev[0].record()
         if full:
-            if evs:
-                evs[0].record()
             env._call("ca_step", env.h, pool[i % 16].data_ptr(), _lib.F_STATS)
-            if evs:
-                evs[1].record()
+            if ev:
+                ev[1].record()
             env._call("ca_observe", env.h)
-            if evs:
-                evs[2].record()
+            if ev:
+                ev[2].record()
         else:
-            if evs:
-                evs[0].record()
             env._call("ca_orca_step", env.h, _lib.F_STATS)
-            if evs:
-                evs[1].record()
+            if ev:
+                ev[1].record()
 
     for i in range(args.warmup):
         one_step(i)
-    nev = 3 if full else 2
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(nev)] for _ in range(args.steps)]
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -142,10 +143,10 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
+    st = env.stats()
     k_step = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))  # ms
     k_obs = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if full else 0.0
-    st = env.stats()
+
     stats_vec = torch.tensor([st["agent_steps"], st["episodes"], st["collisions"], st["obst_collisions"],
                               st["goals_reached"], st["obst_overflow"]], device="cuda", dtype=torch.int64)
     if dist is not None:  # the single collective of the job: per-rank episode statistics over RCCL
@@ -174,7 +175,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_agent": kbytes, "kernel_ms": kms},
-            "kernels_ms": {"step_kernel": k_step, "obs_kernel": k_obs},
+            "kernels_ms": {"step_kernel": k_step, "obs_kernel": k_obs, "serial_sum": k_step + k_obs,
+                           "wall_per_step": dt / args.steps * 1e3},
             "stats": dict(zip(["agent_steps", "episodes", "collisions", "obst_collisions",
                                "goals_reached", "obst_overflow"], [int(v) for v in stats_vec.tolist()])),
             "launch": env.launch_info(),

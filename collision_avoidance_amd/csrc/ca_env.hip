@@ -24,7 +24,8 @@ struct ca_env {
     // [A*N] fp32
     float *pos_x = nullptr, *pos_y = nullptr, *vel_x = nullptr, *vel_y = nullptr, *pref_x = nullptr,
           *pref_y = nullptr, *goal_x = nullptr, *goal_y = nullptr, *goal2_x = nullptr, *goal2_y = nullptr,
-          *reward = nullptr;
+          *reward = nullptr, *orient_x = nullptr, *orient_y = nullptr;
+    bool orient_valid = false;  // orient_x/y match pos/goal (false after the caller edits them)
     int *agent_done = nullptr, *arrive_step = nullptr, *regoal_count = nullptr, *nb_count = nullptr,
         *nb_idx = nullptr, *obst_count = nullptr, *obst_idx = nullptr;
     int *step_count = nullptr, *arena_done = nullptr, *episode = nullptr;
@@ -123,6 +124,7 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.pos_x = e->pos_x; a.pos_y = e->pos_y; a.vel_x = e->vel_x; a.vel_y = e->vel_y;
     a.pref_x = e->pref_x; a.pref_y = e->pref_y; a.goal_x = e->goal_x; a.goal_y = e->goal_y;
     a.goal2_x = e->goal2_x; a.goal2_y = e->goal2_y; a.reward = e->reward;
+    a.orient_x = e->orient_x; a.orient_y = e->orient_y;
     a.agent_done = e->agent_done; a.arrive_step = e->arrive_step; a.regoal_count = e->regoal_count;
     a.nb_count = e->nb_count; a.nb_idx = e->nb_idx; a.obst_count = e->obst_count; a.obst_idx = e->obst_idx;
     a.step_count = e->step_count; a.arena_done = e->arena_done; a.episode = e->episode;
@@ -130,7 +132,7 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.reset_px = nullptr; a.reset_py = nullptr; a.dbg = e->dbg;
     a.reward_scale = c.reward_scale; a.seed = c.seed; a.arena_offset = c.arena_offset;
     a.n_obst = (int)e->h_obst.size(); a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
-    a.K = e->K; a.S = e->S; a.flags = flags;
+    a.K = e->K; a.S = e->S; a.flags = flags; a.a0 = 0; a.a1 = c.n_arenas;
     a.time_step = c.time_step; a.neighbor_dist = c.neighbor_dist; a.time_horizon = c.time_horizon;
     a.time_horizon_obst = c.time_horizon_obst; a.radius = c.radius; a.max_speed = c.max_speed;
     a.max_step = c.max_step; a.done_mode = c.done_mode; a.done_x_thresh = c.done_x_thresh;
@@ -173,13 +175,24 @@ static hipError_t set_lds_attr_k(int BS, size_t lds) {
 }
 
 static hipError_t launch_obs(ca_env* e) {
+    if (!e->orient_valid) {  // positions or goals were edited from outside: re-derive the frame
+        StepArgs a;
+        fill_args(e, a, nullptr, 0);
+        const unsigned an = (unsigned)AN(e);
+        hipLaunchKernelGGL(orient_kernel, dim3((an + 255) / 256), dim3(256), 0, e->stream, a);
+        hipError_t r = hipGetLastError();
+        if (r != hipSuccess) return r;
+        e->orient_valid = true;
+    }
     ObsArgs o;
     o.pos_x = e->pos_x; o.pos_y = e->pos_y; o.vel_x = e->vel_x; o.vel_y = e->vel_y;
-    o.goal_x = e->goal_x; o.goal_y = e->goal_y; o.nb_count = e->nb_count; o.nb_idx = e->nb_idx;
+    o.orient_x = e->orient_x; o.orient_y = e->orient_y; o.nb_count = e->nb_count; o.nb_idx = e->nb_idx;
     o.obst_count = e->obst_count; o.obst_idx = e->obst_idx; o.obst = e->d_obst; o.obs = e->obs;
     o.A = e->cfg.n_arenas; o.N = e->cfg.n_agents; o.S = e->S;
     o.K = e->K > 0 ? e->K : 1;  // nb_idx is allocated with one column when K == 0; counts are all zero
     o.bpa = (o.N + OBS_APB - 1) / OBS_APB;
+    o.a0 = 0;
+    o.radius = e->cfg.radius;
     memcpy(o.rays, e->rays, sizeof o.rays);
     memcpy(o.oct, e->oct, sizeof o.oct);
     const dim3 grid((unsigned)((size_t)o.A * o.bpa)), block(OBS_BS);
@@ -238,7 +251,8 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     host_tables(e);
     const size_t an = AN(e), A = cfg->n_arenas;
     float** f32s[] = {&e->pos_x, &e->pos_y, &e->vel_x, &e->vel_y, &e->pref_x, &e->pref_y, &e->goal_x,
-                      &e->goal_y, &e->goal2_x, &e->goal2_y, &e->reward, &e->tmp_x, &e->tmp_y};
+                      &e->goal_y, &e->goal2_x, &e->goal2_y, &e->reward, &e->tmp_x, &e->tmp_y,
+                      &e->orient_x, &e->orient_y};
     for (auto p : f32s) if (r == hipSuccess) r = dalloc(p, an);
     int** i32s[] = {&e->agent_done, &e->arrive_step, &e->regoal_count, &e->nb_count, &e->obst_count};
     for (auto p : i32s) if (r == hipSuccess) r = dalloc(p, an);
@@ -278,7 +292,8 @@ int ca_destroy(ca_env* e) {
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
     void* bufs[] = {e->pos_x, e->pos_y, e->vel_x, e->vel_y, e->pref_x, e->pref_y, e->goal_x, e->goal_y,
-                    e->goal2_x, e->goal2_y, e->reward, e->tmp_x, e->tmp_y, e->agent_done, e->arrive_step,
+                    e->goal2_x, e->goal2_y, e->reward, e->tmp_x, e->tmp_y, e->orient_x, e->orient_y,
+                    e->agent_done, e->arrive_step,
                     e->regoal_count, e->nb_count, e->nb_idx, e->obst_count, e->obst_idx, e->step_count,
                     e->arena_done, e->episode, e->arena_stats, e->d_obst, e->dbg};
     for (void* b : bufs) if (b) hipFree(b);
@@ -397,6 +412,7 @@ int ca_init_scenario(ca_env* e, int32_t scenario) {
     HIPCHK(e, hipMemset(e->arena_done, 0, (size_t)A * 4));
     HIPCHK(e, hipMemset(e->episode, 0, (size_t)A * 4));
     HIPCHK(e, hipMemset(e->obs, 0, an * CA_OBS_DIM * 4));
+    e->orient_valid = false;
     return CA_OK;
 }
 
@@ -409,6 +425,8 @@ int ca_set(ca_env* e, int32_t field, const void* src, size_t bytes, int32_t src_
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipMemcpyAsync(fi.ptr, src, bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
     if (!src_is_device) HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (field == CA_FLD_POS_X || field == CA_FLD_POS_Y || field == CA_FLD_GOAL_X || field == CA_FLD_GOAL_Y)
+        e->orient_valid = false;
     return CA_OK;
 }
 
@@ -465,6 +483,7 @@ int ca_reset(ca_env* e, const float* pos_x, const float* pos_y, int32_t pos_is_d
     HIPCHK(e, hipGetLastError());
     hipLaunchKernelGGL(reset_arena_kernel, dim3((e->cfg.n_arenas + 255) / 256), dim3(256), 0, e->stream, a);
     HIPCHK(e, hipGetLastError());
+    e->orient_valid = true;
     if (flags & CA_F_OBS) HIPCHK(e, launch_obs(e));
     return CA_OK;
 }
@@ -473,6 +492,7 @@ static int do_step(ca_env* e, const float* actions, uint32_t flags) {
     StepArgs a;
     fill_args(e, a, actions, flags);
     HIPCHK(e, launch_step(e, a));
+    e->orient_valid = true;
     if (flags & CA_F_OBS) HIPCHK(e, launch_obs(e));
     e->steps_done += 1;
     return CA_OK;

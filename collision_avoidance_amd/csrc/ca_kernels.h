@@ -36,6 +36,7 @@ struct StepArgs {
     float *pos_x, *pos_y, *vel_x, *vel_y, *pref_x, *pref_y, *goal_x, *goal_y;
     const float *goal2_x, *goal2_y;
     float* reward;
+    float *orient_x, *orient_y;  // unit vector pos -> goal of the CURRENT state (frame of the observation)
     int *agent_done, *arrive_step, *regoal_count;
     int *nb_count, *nb_idx, *obst_count, *obst_idx;
     int *step_count, *arena_done, *episode;
@@ -49,6 +50,7 @@ struct StepArgs {
     uint64_t seed;
     int64_t arena_offset;
     int n_obst, A, N, P, logP, K, S;
+    int a0, a1;  // this launch covers arenas [a0, a1) (chunked launches on several streams)
     uint32_t flags;
     float time_step, neighbor_dist, time_horizon, time_horizon_obst, radius, max_speed;
     int max_step, done_mode;
@@ -389,8 +391,8 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     const int la = tid >> p.logP;
     const int i = tid & (P - 1);
     const int apb = BS >> p.logP;
-    const int a = blockIdx.x * apb + la;
-    const bool active = (a < p.A) && (i < p.N);
+    const int a = p.a0 + blockIdx.x * apb + la;
+    const bool active = (a < p.a1) && (i < p.N);
     const int N = p.N, K = p.K, S = p.S;
     const int q = active ? a * N + i : 0;
     const int lbase = la << p.logP;
@@ -562,6 +564,7 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     CA_STAMP(9);
     // ---- step counter and done test (env.py:352-365, 404-410; ALAN:118-121, 547-566) ----
     const bool nodone = (p.flags & 8u) != 0;  // CA_F_NODONE
+    bool goal_changed = false;
     int steps = active ? p.step_count[a] : 0;
     if (!p.actions && !nodone) ++steps;
     if (active && !nodone) {
@@ -589,6 +592,7 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
                 p.agent_done[q] = 1;
             }
             p.goal_x[q] = gx; p.goal_y[q] = gy;
+            goal_changed = true;
             atomicAdd(&red[3], 1);
         }
     }
@@ -623,9 +627,19 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
         if (active && (i & 63) == 0)
             atomicAdd(reinterpret_cast<double*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_SUMREW]), r);
     }
+    // orientation of the observation frame (env.py:236): direction to the goal from the final state.
+    // After an ORCA-only step or a reset `pref` already is that vector; otherwise derive it here, once
+    // per agent, instead of in each of the 16 ray lanes of the observation kernel.
+    float ox = pref.x, oy = pref.y;
+    if (active && !do_reset && (p.actions != nullptr || goal_changed)) {
+        double dx, dy;
+        pref_dir64(pos.x, pos.y, gx, gy, &dx, &dy);
+        ox = (float)dx; oy = (float)dy;
+    }
     CA_STAMP(10);
     __syncthreads();  // all lanes have read red[] and episode[]
     if (active) {
+        p.orient_x[q] = ox; p.orient_y[q] = oy;
         p.pos_x[q] = pos.x; p.pos_y[q] = pos.y;
         p.vel_x[q] = vel.x; p.vel_y[q] = vel.y;
         p.pref_x[q] = pref.x; p.pref_y[q] = pref.y;
@@ -672,7 +686,16 @@ __global__ void reset_kernel(const StepArgs p) {
     pref_dir64(pos.x, pos.y, p.goal_x[q], p.goal_y[q], &dx, &dy);
     p.pos_x[q] = pos.x; p.pos_y[q] = pos.y;
     p.pref_x[q] = (float)dx; p.pref_y[q] = (float)dy;
+    p.orient_x[q] = (float)dx; p.orient_y[q] = (float)dy;
     p.agent_done[q] = 0;
+}
+// orientation from scratch (after the caller overwrote positions or goals through ca_set)
+__global__ void orient_kernel(const StepArgs p) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= p.A * p.N) return;
+    double dx, dy;
+    pref_dir64(p.pos_x[q], p.pos_y[q], p.goal_x[q], p.goal_y[q], &dx, &dy);
+    p.orient_x[q] = (float)dx; p.orient_y[q] = (float)dy;
 }
 __global__ void reset_arena_kernel(const StepArgs p) {  // after reset_kernel: per-arena counters
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -699,11 +722,13 @@ __global__ void reset_arena_kernel(const StepArgs p) {  // after reset_kernel: p
 //   4 floats; the 16 lanes of an agent write its 256-B row, a wave stores 1 KiB contiguously.
 // ============================================================================================
 struct ObsArgs {
-    const float *pos_x, *pos_y, *vel_x, *vel_y, *goal_x, *goal_y;
+    const float *pos_x, *pos_y, *vel_x, *vel_y, *orient_x, *orient_y;
     const int *nb_count, *nb_idx, *obst_count, *obst_idx;
     const ObstDev* obst;
     float* obs;
     int A, N, K, S, bpa;  // bpa = workgroups per arena = ceil(N / 16)
+    int a0;               // first arena of this launch
+    float radius;         // of the octagon = agent radius (env.py:31,338)
     float rays[32];       // env.py:321-332
     float oct[32];        // env.py:335-350
 };
@@ -712,8 +737,9 @@ constexpr int OBS_BS = 256;
 constexpr int OBS_APB = OBS_BS / 16;  // agents per workgroup
 
 // LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | nb idx [16][16] | obstacle idx [16][8]
+//              | ray and octagon tables [64] | per-neighbour ray windows [16][16]
 __host__ __device__ inline size_t obs_lds_bytes(int N) {
-    return (size_t)N * 16 + OBS_APB * 16 * 8 + OBS_APB * 16 * 4 + OBS_APB * 8 * 4 + 64 * 4;
+    return (size_t)N * 16 + OBS_APB * 16 * 8 + OBS_APB * 16 * 4 + OBS_APB * 8 * 4 + 64 * 4 + OBS_APB * 16 * 4;
 }
 
 struct SegGeom {  // one segment in the goal-aligned frame, in the reference's intermediate terms
@@ -763,8 +789,9 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     const int tid = threadIdx.x;
     const int g = tid >> 4, r = tid & 15;
     const int N = p.N, K = p.K, S = p.S;
-    const int a = blockIdx.x / p.bpa;
-    const int i = (blockIdx.x - a * p.bpa) * OBS_APB + g;
+    const int ab = blockIdx.x / p.bpa;
+    const int a = p.a0 + ab;
+    const int i = (blockIdx.x - ab * p.bpa) * OBS_APB + g;
     const bool active = i < N;
     const size_t q = (size_t)a * N + (active ? i : 0);
 
@@ -777,6 +804,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     int* s_ob = s_nb + OBS_APB * 16;
     float* s_rays = reinterpret_cast<float*>(s_ob + OBS_APB * 8);  // [32] rays then [32] octagon
     float* s_oct = s_rays + 32;
+    int* s_win = reinterpret_cast<int*>(s_oct + 32);
     if (tid < 32) { s_rays[tid] = p.rays[tid]; s_oct[tid] = p.oct[tid]; }
 
     for (int t = tid; t < N; t += OBS_BS) {
@@ -784,10 +812,10 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         s_px[t] = p.pos_x[qa]; s_py[t] = p.pos_y[qa]; s_vx[t] = p.vel_x[qa]; s_vy[t] = p.vel_y[qa];
     }
     int nn = 0, ns = 0;
-    float gx = 0.0f, gy = 0.0f;
+    float c = 1.0f, s = 0.0f;
     if (active) {
         nn = p.nb_count[q]; ns = p.obst_count[q];
-        gx = p.goal_x[q]; gy = p.goal_y[q];
+        c = p.orient_x[q]; s = -p.orient_y[q];  // utils.py:48-51: cos/sin of -atan2(orientation)
         if (r < nn) s_nb[g * 16 + r] = p.nb_idx[((size_t)a * K + r) * N + i];
         if (r < ns) s_ob[g * 8 + r] = p.obst_idx[((size_t)a * S + r) * N + i];
     }
@@ -795,13 +823,23 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     __syncthreads();
 
     const int M = 8 * nn + ns;
-    float c = 1.0f, s = 0.0f, mx = 0.0f, my = 0.0f;
-    if (M > 0) {
-        mx = s_px[i]; my = s_py[i];
-        double ox, oy;  // env.py:236: orientation = comp_pref_vel of the current state
-        pref_dir64(mx, my, gx, gy, &ox, &oy);
-        c = (float)ox; s = (float)(-oy);  // utils.py:48-51 for a unit vector
+    float mx = 0.0f, my = 0.0f;
+    if (M > 0) { mx = s_px[i]; my = s_py[i]; }
+    // ---- pre-pass, lane per NEIGHBOUR: the rays that can reach its octagon.  All 8 vertices lie on
+    // the circle of radius R around the neighbour, so the rays within asin(R/d) of its direction
+    // are a superset for each of its 8 chords (margin 0.02 dial units = 7.8e-3 rad, see ray_span).
+    for (int k = r; k < nn; k += 16) {
+        const int nb = s_nb[g * 16 + k];
+        const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
+        const float d2 = rx * rx + ry * ry, R = p.radius;
+        const float u = ray_dial(c * rx - s * ry, s * rx + c * ry);
+        const float h = ray_dial(__builtin_amdgcn_sqrtf(fmaxf(d2 - R * R, 0.0f)), -R);  // atan2(R, sqrt(d2-R2))
+        const bool all = !(d2 > 1.0404f * R * R);  // the agent is inside (or within 2 % of) that circle
+        int i0 = (int)ceilf(u - h - 0.02f), i1 = (int)floorf(u + h + 0.02f);
+        if (all || i1 - i0 >= 15) { i0 = 0; i1 = 15; }
+        s_win[g * 16 + k] = (i0 + 64) | ((i1 + 64) << 16);
     }
+    __syncthreads();
     // segment m of this agent in the rotated frame (env.py:283-294, 305-315; utils.py:55-62)
     auto build = [&](int m, SegGeom& sg, float& velx, float& vely, bool want_vel) {
         float x1, y1, x2, y2, vx = 0.0f, vy = 0.0f;
@@ -850,7 +888,12 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         float dum0, dum1;
         build(m, sg, dum0, dum1, false);
         int i0, i1;
-        ray_span(sg.r1x, sg.r1y, sg.r2x, sg.r2y, &i0, &i1);
+        if (m < 8 * nn) {
+            const int w = s_win[g * 16 + (m >> 3)];
+            i0 = (w & 0xffff) - 64; i1 = (w >> 16) - 64;
+        } else {
+            ray_span(sg.r1x, sg.r1y, sg.r2x, sg.r2y, &i0, &i1);
+        }
         for (int ii = i0; ii <= i1; ++ii) {
             const int ray = ii & 15;
             float d, hx, hy;
