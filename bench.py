@@ -76,9 +76,8 @@ def cpu_baseline(workload, mode, seconds):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from collision_avoidance_amd import dist as cad
+    rank, world, local = cad.rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local)
@@ -99,8 +98,9 @@ def main():
     w = scenarios.BENCH_CONFIGS[args.workload]
     A, N = w["n_arenas"], w["n_agents"]
     p = scenarios.bench_params(N, w["neighbor_dist"], w["max_neighbors"])
+    arena_offset, _ = cad.weak_shard(A, rank)  # weak scaling: every GPU owns A arenas of the global range
     env = VecCollisionAvoidanceEnv(A, N, scenario="crowd", params=p, device=local, seed=0,
-                                   arena_offset=rank * A, use_torch=True)
+                                   arena_offset=arena_offset, use_torch=True)
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     pool = (torch.rand((16, A, N), device="cuda", generator=gen) - 0.5)  # actions in [-0.5, 0.5] rad
     full = args.mode == "step"
@@ -147,12 +147,8 @@ def main():
     k_step = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))  # ms
     k_obs = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if full else 0.0
 
-    stats_vec = torch.tensor([st["agent_steps"], st["episodes"], st["collisions"], st["obst_collisions"],
-                              st["goals_reached"], st["obst_overflow"]], device="cuda", dtype=torch.int64)
-    if dist is not None:  # the single collective of the job: per-rank episode statistics over RCCL
-        gathered = [torch.zeros_like(stats_vec) for _ in range(world)]
-        dist.all_gather(gathered, stats_vec)
-        stats_vec = torch.stack(gathered).sum(0)
+    # the single collective of the job: per-rank statistics (RCCL all_gather over xGMI when N > 1)
+    per_rank_stats, total_stats = cad.gather_stats(st, device="cuda")
     if rank == 0:
         agents = A * N
         value = world * agents * args.steps / dt
@@ -177,8 +173,7 @@ def main():
                          "algorithmic_bytes_per_agent": kbytes, "kernel_ms": kms},
             "kernels_ms": {"step_kernel": k_step, "obs_kernel": k_obs, "serial_sum": k_step + k_obs,
                            "wall_per_step": dt / args.steps * 1e3},
-            "stats": dict(zip(["agent_steps", "episodes", "collisions", "obst_collisions",
-                               "goals_reached", "obst_overflow"], [int(v) for v in stats_vec.tolist()])),
+            "stats": {k: total_stats[k] for k in cad.STAT_KEYS},
             "launch": env.launch_info(),
         }
         if world == 1 and not args.no_cpu_baseline:

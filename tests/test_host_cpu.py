@@ -1,0 +1,97 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol that
+include/ca_env.h declares, struct layouts match, errors are loud, scenario geometry restates the
+reference's constants.  No compute call is made (there is no GPU here and no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from collision_avoidance_amd import _lib, scenarios
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header():
+    return open(os.path.join(ROOT, "include", "ca_env.h")).read()
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(ca_[a-z_0-9]+)\s*\(", _header(), re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_enums_and_struct_layout_match_header():
+    h = _header()
+    fields = re.search(r"enum ca_field \{(.*?)CA_FLD__COUNT", h, re.S).group(1)
+    names = re.findall(r"(CA_FLD_[A-Z0-9_]+)", fields)
+    for i, n in enumerate(names):
+        assert getattr(_lib, n[3:]) == i, n
+    for macro in ("CA_OBS_DIM", "CA_MAX_NEIGHBORS", "CA_MAX_OBST_NEIGHBORS", "CA_MAX_AGENTS"):
+        assert int(re.search(r"#define %s (\d+)" % macro, h).group(1)) == getattr(_lib, macro[3:])
+    for macro, val in (("CA_F_OBS", _lib.F_OBS), ("CA_F_STATS", _lib.F_STATS), ("CA_F_AUTORESET", _lib.F_AUTORESET),
+                       ("CA_F_NODONE", _lib.F_NODONE)):
+        assert int(re.search(r"#define %s (\d+)u" % macro, h).group(1)) == val
+    cfg = re.search(r"typedef struct ca_config \{(.*?)\} ca_config;", h, re.S).group(1)
+    cfg = re.sub(r"/\*.*?\*/", "", cfg, flags=re.S)
+    decl = []
+    for ty, rest in re.findall(r"(int32_t|int64_t|uint64_t|double|float)\s+([^;]+);", cfg):
+        decl += [(v.strip(), ty) for v in rest.split(",")]
+    ctype = {"int32_t": C.c_int32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "double": C.c_double, "float": C.c_float}
+    assert [(n, ctype[t]) for n, t in decl] == list(_lib.Config._fields_)
+    assert C.sizeof(_lib.Config) == 112
+    # the oracle's config mirrors it field for field (tests fill both from one dict)
+    from oracle import oracle as o
+    assert [f[0] for f in o.Config._fields_] == [f[0] for f in _lib.Config._fields_]
+
+
+def test_no_cpu_fallback_is_loud():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from collision_avoidance_amd.vec_env import VecCollisionAvoidanceEnv
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        VecCollisionAvoidanceEnv(2, 4, use_torch=False)
+    from collision_avoidance_amd.envs import Collision_Avoidance_Env
+    with pytest.raises(RuntimeError):
+        Collision_Avoidance_Env(numAgents=3)
+
+
+def test_argument_validation_without_gpu():
+    L = _lib.load()
+    h = C.c_void_p()
+    bad = _lib.Config(n_arenas=0, n_agents=4, max_obst_neighbors=1, **scenarios.env_params())
+    assert L.ca_create(C.byref(bad), 0, None, C.byref(h)) == -5 and not h.value
+    assert b"out of range" in L.ca_last_error(None)
+    bad = _lib.Config(n_arenas=1, n_agents=4, max_obst_neighbors=1, **dict(scenarios.env_params(), max_neighbors=17))
+    assert L.ca_create(C.byref(bad), 0, None, C.byref(h)) == -5
+    assert L.ca_create(None, 0, None, C.byref(h)) == -1
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under collision_avoidance_amd/ may import it."""
+    pkg = os.path.join(ROOT, "collision_avoidance_amd")
+    banned = re.compile(r"(^\s*(from|import)\s+oracle\b|from\s+\.+\s*import\s+oracle|#include\s*[\"<].*oracle|"
+                        r"libca_oracle|\borc_[a-z_]+\s*\(|rvo2_shim)", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not banned.search(src), os.path.join(dirpath, f)
+
+
+def test_scenario_geometry():
+    assert scenarios.obstacles("doorway", 10) == [
+        [(-15.0, 0.0), (-15.0, 10), (10, 10), (10, 0.0)],
+        [(2.0, 0.0), (2.5, 0.0), (2.5, 4.4), (2.0, 4.4)],
+        [(2.0, 5.6), (2.5, 5.6), (2.5, 10.0), (2.0, 10.0)]]
+    assert scenarios.crowd_envsize(64) == 16.0 and scenarios.crowd_envsize(16) == 8.0
+    p = scenarios.bench_params(64, 5.0, 10)
+    assert p["done_mode"] == scenarios.DONE_REGOAL and p["max_step"] == 0 and p["goal_x1"] == 16.0
+    assert scenarios.alan_params(8, "circle")["max_step"] == int((10 / (1 / 60.)) * 8)
+    with pytest.raises(ValueError):
+        scenarios.obstacles("nope", 4)
