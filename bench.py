@@ -155,7 +155,7 @@ def main():
         if full and k_obs >= k_step:
             dom, kms, kbytes = "obs_kernel", k_obs, BYTES_OBS_KERNEL
         else:
-            dom, kms, kbytes = "step_kernel", k_step, (BYTES_STEP_KERNEL_FULL if full else BYTES_STEP_KERNEL_ORCA)
+            dom, kms, kbytes = "nbr_kernel+step_kernel", k_step, (BYTES_STEP_KERNEL_FULL if full else BYTES_STEP_KERNEL_ORCA)
         achieved = agents * kbytes / (kms * 1e-3) / 1e9
         out = {
             "metric": "agent-steps/sec (whole node), %d arenas x %d agents per GPU" % (A, N),
@@ -171,7 +171,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_agent": kbytes, "kernel_ms": kms},
-            "kernels_ms": {"step_kernel": k_step, "obs_kernel": k_obs, "serial_sum": k_step + k_obs,
+            "kernels_ms": {"nbr_kernel+step_kernel": k_step, "obs_kernel": k_obs, "serial_sum": k_step + k_obs,
                            "wall_per_step": dt / args.steps * 1e3},
             "stats": {k: total_stats[k] for k in cad.STAT_KEYS},
             "launch": env.launch_info(),

@@ -143,12 +143,17 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
 template <int KMAX>
 static hipError_t launch_step_k(ca_env* e, const StepArgs& a) {
     const dim3 grid(e->grid), block(e->BS);
-    switch (e->BS) {
-        case 64: hipLaunchKernelGGL((step_kernel<KMAX, 64>), grid, block, e->lds, e->stream, a); break;
-        case 128: hipLaunchKernelGGL((step_kernel<KMAX, 128>), grid, block, e->lds, e->stream, a); break;
-        case 256: hipLaunchKernelGGL((step_kernel<KMAX, 256>), grid, block, e->lds, e->stream, a); break;
-        case 512: hipLaunchKernelGGL((step_kernel<KMAX, 512>), grid, block, e->lds, e->stream, a); break;
-        default: hipLaunchKernelGGL((step_kernel<KMAX, 1024>), grid, block, e->lds, e->stream, a); break;
+    switch (e->BS) {  // neighbour search, then lines + LP + integration + reward/done on the same stream
+        case 64: hipLaunchKernelGGL((nbr_kernel<KMAX, 64>), grid, block, 0, e->stream, a);
+                 hipLaunchKernelGGL((step_kernel<KMAX, 64>), grid, block, e->lds, e->stream, a); break;
+        case 128: hipLaunchKernelGGL((nbr_kernel<KMAX, 128>), grid, block, 0, e->stream, a);
+                  hipLaunchKernelGGL((step_kernel<KMAX, 128>), grid, block, e->lds, e->stream, a); break;
+        case 256: hipLaunchKernelGGL((nbr_kernel<KMAX, 256>), grid, block, 0, e->stream, a);
+                  hipLaunchKernelGGL((step_kernel<KMAX, 256>), grid, block, e->lds, e->stream, a); break;
+        case 512: hipLaunchKernelGGL((nbr_kernel<KMAX, 512>), grid, block, 0, e->stream, a);
+                  hipLaunchKernelGGL((step_kernel<KMAX, 512>), grid, block, e->lds, e->stream, a); break;
+        default: hipLaunchKernelGGL((nbr_kernel<KMAX, 1024>), grid, block, 0, e->stream, a);
+                 hipLaunchKernelGGL((step_kernel<KMAX, 1024>), grid, block, e->lds, e->stream, a); break;
     }
     return hipGetLastError();
 }

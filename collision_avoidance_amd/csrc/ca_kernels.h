@@ -331,26 +331,36 @@ __device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, 
     return true;
 }
 
-// Sorted insertion into a register-resident list kept ascending; a new key goes behind every key
-// <= it and the last entry falls off.  Candidates arrive in increasing index order, so "behind
-// equal keys" is the (distance, index) order of the contract.  Every slot is computed from the OLD
-// list alone -- new[k] = old[k] if old[k] <= x, else x if old[k-1] <= x, else old[k-1] -- so the
-// slots are independent instructions (no carry chain).  A list shorter than the array is stored
-// RIGHT-ALIGNED behind dummy -inf slots (which never move): its largest key is then always the
-// last element, a compile-time index, and the array never has to live in scratch memory.
+// Sorted insertion into a register-resident list kept ascending, the last entry falling off.
+// An entry is the 64-bit key (distance bits << 32 | index) held in a double register pair: for
+// non-negative floats the bit pattern is monotone, so key order IS the (distance, index) order of the
+// contract (App. A.2: ascending distance, ties to the lower index), and as positive, never-NaN doubles
+// the keys are ordered by v_min_f64 / v_max_f64.  Insertion is then, for every slot independently and
+// in place,   new[k] = max(old[k-1], min(old[k], x))   -- two VALU instructions per slot, no compare
+// masks, no register copies.  (Inline asm because the compiler would add a canonicalising
+// v_max_f64 v,v,v per operand; keys are never NaN so nothing needs quieting.)
+// A list shorter than the array is stored RIGHT-ALIGNED behind dummy -inf slots (which never move):
+// its largest key is then always the last element, a compile-time index.
+__device__ __forceinline__ double key_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double key_max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double make_key(float d, int idx) {
+    return __longlong_as_double((long long)(((unsigned long long)__float_as_uint(d) << 32) | (unsigned)idx));
+}
+__device__ __forceinline__ float key_dist(double k) { return __uint_as_float((unsigned)((unsigned long long)__double_as_longlong(k) >> 32)); }
+__device__ __forceinline__ int key_index(double k) { return (int)(unsigned)(unsigned long long)__double_as_longlong(k); }
 template <int MAXN>
-__device__ __forceinline__ void sorted_insert(float (&d)[MAXN], int (&idx)[MAXN], float x, int xi) {
-    float od[MAXN]; int oi[MAXN]; bool le[MAXN];
+__device__ __forceinline__ void sorted_insert(double (&key)[MAXN], double x) {
 #pragma unroll
-    for (int k = 0; k < MAXN; ++k) { od[k] = d[k]; oi[k] = idx[k]; le[k] = od[k] <= x; }
-#pragma unroll
-    for (int k = 0; k < MAXN; ++k) {
-        const bool ple = (k == 0) ? true : le[k - 1];
-        const float sd = (k == 0) ? x : od[k - 1];
-        const int si = (k == 0) ? xi : oi[k - 1];
-        d[k] = le[k] ? od[k] : (ple ? x : sd);
-        idx[k] = le[k] ? oi[k] : (ple ? xi : si);
-    }
+    for (int k = MAXN - 1; k >= 1; --k) key[k] = key_max(key[k - 1], key_min(key[k], x));
+    key[0] = key_min(key[0], x);
 }
 template <int MAXN>
 __device__ __forceinline__ int pick(const int (&v)[MAXN], int k) {
@@ -359,6 +369,91 @@ __device__ __forceinline__ int pick(const int (&v)[MAXN], int k) {
     for (int j = 1; j < MAXN; ++j) r = (k == j) ? v[j] : r;
     return r;
 }
+// ============================================================================================
+// Neighbour search for every agent (App. A.2): the obstacle edges within range and
+// the K nearest agents, written as the lists [A,S,N] / [A,K,N] that the solve kernel and the
+// observation read.  A kernel of its own because it needs almost no LDS (the arena's positions,
+// 8 B per lane): it runs at full occupancy and is issue-bound, whereas the solve kernel is tied to
+// its 16 B x (K+S) line table per lane.
+// ============================================================================================
+template <int KMAX, int BS>
+__global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
+    __shared__ float s_px[BS];
+    __shared__ float s_py[BS];
+    const int tid = threadIdx.x;
+    const int P = p.P;
+    const int la = tid >> p.logP;
+    const int i = tid & (P - 1);
+    const int apb = BS >> p.logP;
+    const int a = p.a0 + blockIdx.x * apb + la;
+    const bool active = (a < p.a1) && (i < p.N);
+    const int N = p.N, K = p.K, S = p.S;
+    const int q = active ? a * N + i : 0;
+    const int lbase = la << p.logP;
+    V2 pos = mk(0.0f, 0.0f);
+    if (active) pos = mk(p.pos_x[q], p.pos_y[q]);
+    s_px[tid] = pos.x; s_py[tid] = pos.y;
+    __syncthreads();
+
+    const float INF = __int_as_float(0x7f800000);
+    // ---- obstacle neighbours (App. A.2): brute force over the edge table ----
+    const int sofs = SMAX - S;  // the S-entry list is right-aligned in the register array
+    const double KEY_EMPTY = __longlong_as_double(0x7F800000FFFFFFFFll);  // (+inf, -1)
+    const double KEY_DUMMY = __longlong_as_double((long long)0xFFF0000000000000ull);  // -inf: never moves
+    double okey[SMAX];
+#pragma unroll
+    for (int k = 0; k < SMAX; ++k) okey[k] = (k < sofs) ? KEY_DUMMY : KEY_EMPTY;
+    int oin = 0;
+    {
+        const float rangeSq = sqr(p.time_horizon_obst * p.max_speed + p.radius);
+        for (int e = 0; e < p.n_obst; ++e) {
+            const ObstDev o1 = p.obst[e];
+            const V2 a1 = mk(o1.px, o1.py), a2 = mk(o1.qx, o1.qy);
+            const float alol = leftOf(a1, a2, pos);
+            const float dsl = sqr(alol) / absSq(a2 - a1);
+            if (active && dsl < rangeSq && alol < 0.0f) {
+                const float dsq = distSqPointSegment(a1, a2, pos);
+                if (dsq < rangeSq) {
+                    ++oin;
+                    sorted_insert<SMAX>(okey, make_key(dsq, e));
+                }
+            }
+        }
+    }
+    const int ocnt = oin < S ? oin : S;
+
+    // ---- agent neighbours (App. A.2): K nearest within neighbor_dist, ties -> lower index ----
+    const int kofs = KMAX - K;  // the K-entry list is right-aligned in the register array
+    double nkey[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) nkey[k] = (k < kofs) ? KEY_DUMMY : KEY_EMPTY;
+    int ncnt = 0;
+    if (K > 0) {
+        float rangeSq = sqr(p.neighbor_dist);
+        for (int j = 0; j < N; ++j) {
+            const V2 o = mk(s_px[lbase + j], s_py[lbase + j]);
+            const float dsq = absSq(pos - o);
+            if (active && j != i && dsq < rangeSq) {
+                sorted_insert<KMAX>(nkey, make_key(dsq, j));
+                if (ncnt < K) ++ncnt;
+                if (ncnt == K) rangeSq = key_dist(nkey[KMAX - 1]);
+            }
+        }
+    }
+
+    if (active) {
+        if (oin > S) atomicAdd(reinterpret_cast<int*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_OVERFLOW]), 1);
+        p.nb_count[q] = ncnt;
+        p.obst_count[q] = ocnt;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k >= kofs) p.nb_idx[((size_t)a * K + (k - kofs)) * N + i] = key_index(nkey[k]);
+#pragma unroll
+        for (int k = 0; k < SMAX; ++k)
+            if (k >= sofs) p.obst_idx[((size_t)a * S + (k - sofs)) * N + i] = key_index(okey[k]);
+    }
+}
+
 // LDS carve-up of the step kernel (bytes): lines | px py vx vy | misc ints
 __host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S) {
     return (size_t)BS * ((size_t)(K + S) * 16 + 16 + 16);
@@ -431,61 +526,23 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     __syncthreads();
 
     CA_STAMP(1);
-    const float INF = __int_as_float(0x7f800000);
-    // ---- obstacle neighbours (App. A.2): brute force over the edge table ----
-    const int sofs = SMAX - S;  // the S-entry list is right-aligned in the register array
-    float od[SMAX]; int oi[SMAX];
-#pragma unroll
-    for (int k = 0; k < SMAX; ++k) { od[k] = (k < sofs) ? -INF : INF; oi[k] = -1; }
-    int oin = 0;
-    {
-        const float rangeSq = sqr(p.time_horizon_obst * p.max_speed + p.radius);
-        for (int e = 0; e < p.n_obst; ++e) {
-            const ObstDev o1 = p.obst[e];
-            const V2 a1 = mk(o1.px, o1.py), a2 = mk(o1.qx, o1.qy);
-            const float alol = leftOf(a1, a2, pos);
-            const float dsl = sqr(alol) / absSq(a2 - a1);
-            if (active && dsl < rangeSq && alol < 0.0f) {
-                const float dsq = distSqPointSegment(a1, a2, pos);
-                if (dsq < rangeSq) {
-                    ++oin;
-                    sorted_insert<SMAX>(od, oi, dsq, e);
-                }
-            }
-        }
-    }
-    const int ocnt = oin < S ? oin : S;
-
+    // ---- neighbour lists of this step (App. A.2), produced by nbr_kernel ----
+    const int ocnt = active ? p.obst_count[q] : 0;
+    const int ncnt = active ? p.nb_count[q] : 0;
     CA_STAMP(2);
-    // ---- agent neighbours (App. A.2): K nearest within neighbor_dist, ties -> lower index ----
-    const int kofs = KMAX - K;  // the K-entry list is right-aligned in the register array
-    float nd[KMAX]; int ni[KMAX];
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) { nd[k] = (k < kofs) ? -INF : INF; ni[k] = -1; }
-    int ncnt = 0;
-    if (K > 0) {
-        float rangeSq = sqr(p.neighbor_dist);
-        for (int j = 0; j < N; ++j) {
-            const V2 o = mk(s_px[lbase + j], s_py[lbase + j]);
-            const float dsq = absSq(pos - o);
-            if (active && j != i && dsq < rangeSq) {
-                sorted_insert<KMAX>(nd, ni, dsq, j);
-                if (ncnt < K) ++ncnt;
-                if (ncnt == K) rangeSq = nd[KMAX - 1];
-            }
-        }
-    }
-
     CA_STAMP(3);
     // ---- ORCA lines -> LDS table ----
     int nl = 0;
     const float R = p.radius;
     {
         const float invTO = 1.0f / p.time_horizon_obst;
+        int e_next = (ocnt > 0) ? p.obst_idx[((size_t)a * S + 0) * N + i] : 0;
         for (int s = 0; s < S; ++s) {
             if (s < ocnt) {
+                const int e = e_next;
+                if (s + 1 < ocnt) e_next = p.obst_idx[((size_t)a * S + (s + 1)) * N + i];
                 Line line;
-                if (obst_orca_line(p.obst, pick<SMAX>(oi, sofs + s), pos, vel, R, invTO, ls, nl, line)) {
+                if (obst_orca_line(p.obst, e, pos, vel, R, invTO, ls, nl, line)) {
                     ls.put(nl, line);
                     ++nl;
                 }
@@ -497,9 +554,11 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     {
         const float invT = 1.0f / p.time_horizon;
         const float invDt = 1.0f / p.time_step;
+        int j_next = (ncnt > 0) ? p.nb_idx[((size_t)a * K + 0) * N + i] : 0;
         for (int k = 0; k < K; ++k) {
             if (k < ncnt) {
-                const int j = lbase + pick<KMAX>(ni, kofs + k);
+                const int j = lbase + j_next;
+                if (k + 1 < ncnt) j_next = p.nb_idx[((size_t)a * K + (k + 1)) * N + i];
                 const Line line = agent_orca_line(pos, vel, mk(s_px[j], s_py[j]), mk(s_vx[j], s_vy[j]), R, invT, invDt);
                 ls.put(nl, line);
                 ++nl;
@@ -528,7 +587,6 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     int* red = s_misc + la * 4;  // per-arena: [0] not-done agents, [1] pairs, [2] wall hits, [3] goals
 
     if (active) {
-        if (oin > S) atomicAdd(reinterpret_cast<int*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_OVERFLOW]), 1);
         if (p.flags & 2u) {  // CA_F_STATS
             int pairs = 0;
             const float crSq = sqr(R + R);
@@ -643,14 +701,6 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
         p.pos_x[q] = pos.x; p.pos_y[q] = pos.y;
         p.vel_x[q] = vel.x; p.vel_y[q] = vel.y;
         p.pref_x[q] = pref.x; p.pref_y[q] = pref.y;
-        p.nb_count[q] = ncnt;
-        p.obst_count[q] = ocnt;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-            if (k >= kofs) p.nb_idx[((size_t)a * K + (k - kofs)) * N + i] = ni[k];
-#pragma unroll
-        for (int k = 0; k < SMAX; ++k)
-            if (k >= sofs) p.obst_idx[((size_t)a * S + (k - sofs)) * N + i] = oi[k];
         if (i == 0) {
             unsigned long long* st = p.arena_stats + (size_t)a * ST_STRIDE;
             if (red[1]) st[ST_COLL] += (unsigned)red[1];

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: where does a step-kernel wave spend its cycles?  Builds a CA_STAMPS variant of the
+"""Diagnostic: where does a step-kernel (solve) wave spend its cycles?  Builds a CA_STAMPS variant of the
 library into gpurun_out/ (never the product build), runs the bench workload for a few steps and
 prints the mean share of each phase.  Usage (GPU box): python tools/stamps.py [C3|C2|C5] [step|orca]"""
 import ctypes as C
@@ -28,7 +28,7 @@ env = VecCollisionAvoidanceEnv(A, N, "crowd", scenarios.bench_params(N, w["neigh
                                use_torch=False)
 env.L.ca_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
 rng = np.random.RandomState(0)
-names = ["load+pref+stage", "obst nbrs", "agent scan", "obst lines", "agent lines", "LP2", "LP3+integrate",
+names = ["load+pref+stage", "list counts", "(unused)", "obst lines", "agent lines", "LP2", "LP3+integrate",
          "barrier+stats", "reward/pref", "done test+reduce", "tail sync+write"]
 acc = []
 for s in range(120):
