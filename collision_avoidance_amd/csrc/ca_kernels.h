@@ -78,7 +78,10 @@ struct PrivLines {
     __device__ __forceinline__ Line get(int j) const { return p[j]; }
 };
 
-// App. A.5 LP1
+// App. A.5 LP1.  The contract returns false at the first line that makes the interval empty (or a
+// parallel line that excludes it); tLeft only grows and tRight only shrinks, so accumulating the
+// same conditions in a flag and finishing the loop gives the same verdict -- and a branch-free body
+// whose loads and divisions for consecutive lines overlap (the loop is unrolled by two).
 template <class LS>
 __device__ __forceinline__ bool lp1(const LS& ls, int lineNo, float radius, V2 opt, bool dirOpt, V2& result) {
     const Line L = ls.get(lineNo);
@@ -88,22 +91,25 @@ __device__ __forceinline__ bool lp1(const LS& ls, int lineNo, float radius, V2 o
     const float sq = sqrtf(disc);
     float tLeft = -dp - sq;
     float tRight = -dp + sq;
-    Line Mn = L;
-    if (lineNo > 0) Mn = ls.get(0);
-    for (int j = 0; j < lineNo; ++j) {
-        const Line M = Mn;
-        if (j + 1 < lineNo) Mn = ls.get(j + 1);  // next line is in flight while this one is used
+    bool failed = false;
+    auto clip = [&](const Line& M) {
         const float den = det(L.dir, M.dir);
         const float num = det(M.dir, L.point - M.point);
-        if (fabsf(den) <= EPS) {
-            if (num < 0.0f) return false;
-            continue;
-        }
+        const bool par = fabsf(den) <= EPS;
         const float t = num / den;
-        if (den >= 0.0f) tRight = (t < tRight) ? t : tRight;
-        else tLeft = (tLeft < t) ? t : tLeft;
-        if (tLeft > tRight) return false;
+        const bool right = !par && den >= 0.0f, left = !par && !(den >= 0.0f);
+        tRight = (right && t < tRight) ? t : tRight;
+        tLeft = (left && tLeft < t) ? t : tLeft;
+        failed = failed || (par ? (num < 0.0f) : (tLeft > tRight));
+    };
+    int j = 0;
+    for (; j + 1 < lineNo; j += 2) {
+        const Line M0 = ls.get(j), M1 = ls.get(j + 1);
+        clip(M0);
+        clip(M1);
     }
+    if (j < lineNo) clip(ls.get(j));
+    if (failed) return false;
     if (dirOpt) {
         if (dot(opt, L.dir) > 0.0f) result = L.point + tRight * L.dir;
         else result = L.point + tLeft * L.dir;

@@ -243,6 +243,9 @@ void lp3(const std::vector<Line>& lines, int numObst, int begin, float radius, V
     }
 }
 
+/* diagnostics: how often the infeasible path (LP3) is taken, and how many lines it re-solves */
+static uint64_t g_dbg[4] = {0, 0, 0, 0};
+
 /* App. A.3 + A.4 + the LP call sequence of A.5 */
 void compute_new_velocity(Arena& a, const std::vector<ObstVertex>& obst, int i, float timeStep) {
     const AgentParams& P = a.prm[i];
@@ -411,7 +414,8 @@ void compute_new_velocity(Arena& a, const std::vector<ObstVertex>& obst, int i, 
     }
     V2 nv = mk(0.0f, 0.0f);
     const int fail = lp2(lines, P.maxSpeed, a.pref[i], false, nv);
-    if (fail < (int)lines.size()) lp3(lines, numObstLines, fail, P.maxSpeed, nv);
+    g_dbg[0] += 1;
+    if (fail < (int)lines.size()) { g_dbg[1] += 1; g_dbg[2] += lines.size() - fail; lp3(lines, numObstLines, fail, P.maxSpeed, nv); }
     a.newVel[i] = nv;
 }
 
@@ -1187,6 +1191,7 @@ void orc_comp_laser_f32(const float* ray_ends, const float* segs, int32_t m, con
     if (len == 0) { ox = 1; oy = 0; } else { ox = o[0] / len; oy = o[1] / len; }
     comp_laser<float>(ray_ends, (const Seg<float>*)(const void*)segs, m, (float)ox, (float)(-oy), out);
 }
+void orc_debug_counters(uint64_t* out4) { for (int i = 0; i < 4; ++i) out4[i] = g_dbg[i]; }
 void orc_sincos64(double a, double* s, double* c) { sincos64(a, s, c); }
 void orc_pref_dir64(float px, float py, float gx, float gy, double* out2) { pref_dir64(px, py, gx, gy, &out2[0], &out2[1]); }
 void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out4) {
