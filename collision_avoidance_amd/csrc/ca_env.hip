@@ -361,7 +361,7 @@ int ca_set_obstacles(ca_env* e, const float* verts_xy, const int32_t* poly_sizes
 
 int ca_init_scenario(ca_env* e, int32_t scenario) {
     if (!e) return CA_EINVAL;
-    if (scenario < 0 || scenario > 2) return fail(e, CA_EINVAL, "ca_init_scenario: unknown scenario %d", scenario);
+    if (scenario < 0 || scenario > 6) return fail(e, CA_EINVAL, "ca_init_scenario: unknown scenario %d", scenario);
     const ca_config& c = e->cfg;
     const int A = c.n_arenas, N = c.n_agents;
     const size_t an = AN(e);
@@ -391,6 +391,46 @@ int ca_init_scenario(ca_env* e, int32_t scenario) {
                 gy[q] = (float)(E / 2 + R * std::sin(theta + M_PI));
                 g2x[q] = gx[q]; g2y[q] = gy[q];
                 theta += (2.0 * M_PI) / N;
+            } else if (scenario >= CA_SCN_CONGESTED) {  // ALAN:175-193, 213-258, 333-357, 377-416
+                const double E = (scenario == CA_SCN_CONGESTED) ? std::sqrt(2 * r * N) * 3
+                               : (scenario == CA_SCN_BLOCKS) ? 3 * r * N : std::sqrt(2 * r * N) * 10;
+                double x = 0, y = 0, tx = 0, ty = 0, t2x = 0, t2y = 0;
+                if (scenario == CA_SCN_CONGESTED) {
+                    rng2(c.seed, g, i, RNG_POS, 0, &u0, &u1);
+                    x = uniform64(E * 0.2, E, u0); y = uniform64(0.0, E, u1);
+                    tx = 0.1 * E - 1.0; ty = E / 2; t2x = 0.1 * E - E; t2y = E / 2;
+                } else if (scenario == CA_SCN_INCOMING) {
+                    if (i == 0) {
+                        x = 0.1 * E; y = E / 2; tx = t2x = 0.9 * E; ty = t2y = E / 2;
+                    } else {  // the block of N-1 agents, column by column (ALAN:232-258)
+                        const double len = std::sqrt((double)(N - 1)), x_inc = 3 * r, y_inc = 2.1 * r;
+                        const double y_start = E / 2 - ((y_inc * len) / 2);
+                        double x_pos = 0.8 * E, y_pos = y_start;
+                        for (int k = 1; k < i; ++k) {
+                            y_pos += y_inc;
+                            if (y_pos > y_start + y_inc * len) { x_pos += x_inc; y_pos = y_start; }
+                        }
+                        x = x_pos; y = y_pos; tx = t2x = x_pos - 0.7 * E; ty = t2y = y_pos;
+                    }
+                } else if (scenario == CA_SCN_BLOCKS) {
+                    double y_pos = 1.5 * r;
+                    for (int k = 0; k < i; ++k) y_pos += 3 * r;
+                    x = 1.5 * r; y = y_pos; tx = t2x = E - 1.5 * r; ty = t2y = y_pos;
+                } else {  // deadlock: two queues facing each other through a tube
+                    const int half = N / 2;
+                    if (i < half) {
+                        double pos_x = 0.2 * E;
+                        for (int k = 0; k < i; ++k) pos_x += -3 * r;
+                        x = pos_x; tx = 0.9 * E; t2x = 0.9 * E + E;
+                    } else {
+                        double pos_x = 0.8 * E;
+                        for (int k = half; k < i; ++k) pos_x += 3 * r;
+                        x = pos_x; tx = 0.1 * E; t2x = 0.1 * E - E;
+                    }
+                    y = E / 2; ty = t2y = E / 2;
+                }
+                px[q] = (float)x; py[q] = (float)y; gx[q] = (float)tx; gy[q] = (float)ty;
+                g2x[q] = (float)t2x; g2y[q] = (float)t2y;
             } else {  // env.py:86-95, 361
                 const double E = 10.0;
                 rng2(c.seed, g, i, RNG_POS, 0, &u0, &u1);

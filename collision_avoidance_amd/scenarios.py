@@ -6,8 +6,10 @@ envs/collision_avoidence_env.py, ALAN = ALAN/ALAN_true.py).
 """
 from math import pi, sqrt
 
-SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY = 0, 1, 2
-SCENARIO_IDS = {"crowd": SCN_CROWD, "circle": SCN_CIRCLE, "doorway": SCN_DOORWAY}
+SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN_DEADLOCK = range(7)
+SCENARIO_IDS = {"crowd": SCN_CROWD, "circle": SCN_CIRCLE, "doorway": SCN_DOORWAY, "congested": SCN_CONGESTED,
+                "incoming": SCN_INCOMING, "blocks": SCN_BLOCKS, "deadlock": SCN_DEADLOCK}
+SCENARIO_NAMES = {v: k for k, v in SCENARIO_IDS.items()}
 
 DONE_XLESS, DONE_GOAL, DONE_REGOAL = 0, 1, 2
 
@@ -27,8 +29,57 @@ def circle_envsize(n_agents, radius=0.5):
     return 2 * (radius * 3 * n_agents / (2 * pi)) + 4 * radius
 
 
-def obstacles(scenario, n_agents, radius=0.5):
-    """Obstacle polygons of a scenario as lists of (x, y)."""
+def envsize(scenario, n_agents, radius=0.5):
+    """The world size each ALAN scenario derives from the agent count."""
+    scenario = SCENARIO_NAMES.get(scenario, scenario)
+    if scenario == "crowd":
+        return crowd_envsize(n_agents, radius)
+    if scenario == "circle":
+        return circle_envsize(n_agents, radius)
+    if scenario == "congested":
+        return sqrt(2 * radius * n_agents) * 3          # ALAN:177
+    if scenario in ("incoming", "deadlock"):
+        return sqrt(2 * radius * n_agents) * 10         # ALAN:215, 379
+    if scenario == "blocks":
+        return 3 * radius * n_agents                    # ALAN:335
+    if scenario == "doorway":
+        return 10
+    raise ValueError("unknown scenario %r" % (scenario,))
+
+
+def obstacles(scenario, n_agents, radius=0.5, seed=0):
+    """Obstacle polygons of a scenario as lists of (x, y).  `seed` places the four random blocks of the
+    "blocks" scenario (ALAN:364-372; the same layout for every arena of a handle)."""
+    scenario = SCENARIO_NAMES.get(scenario, scenario)
+    r = radius
+    if scenario == "congested":                                            # ALAN:195-208
+        e = envsize(scenario, n_agents, r)
+        return [_rect((-e, 0.0), (-e, e), (e, e), (e, 0.0)),
+                _rect((0.1 * e, 0.0), (0.1 * e + 0.5, 0.0), (0.1 * e + 0.5, e / 2 - 1.25 * r), (0.1 * e, e / 2 - 1.25 * r)),
+                _rect((0.1 * e, e / 2 + 1.25 * r), (0.1 * e + 0.5, e / 2 + 1.25 * r), (0.1 * e + 0.5, e), (0.1 * e, e))]
+    if scenario == "incoming":                                             # ALAN:263-265
+        e = envsize(scenario, n_agents, r)
+        return [_rect((0.0, 0.0), (0.0, e), (e, e), (e, 0.0))]
+    if scenario == "blocks":                                               # ALAN:359-372
+        import numpy as np
+        e = envsize(scenario, n_agents, r)
+        polys = [_rect((0.0, 0.0), (0.0, e), (e, e), (e, 0.0))]
+        rng = np.random.RandomState(seed)
+        b = e / (4 * 2)
+        for _ in range(4):
+            x, y = float(rng.uniform(b, e - b)), float(rng.uniform(0, e))
+            polys.append(_rect((x - b / 2, y - b / 2), (x + b / 2, y - b / 2), (x + b / 2, y + b / 2), (x - b / 2, y + b / 2)))
+        return polys
+    if scenario == "deadlock":                                             # ALAN:418-455
+        e = envsize(scenario, n_agents, r)
+        lo, hi = e / 2 - 1.25 * r, e / 2 + 1.25 * r
+        return [_rect((-e, 0.0), (-e, e), (2 * e, e), (2 * e, 0.0)),
+                _rect((0.0, 0.0), (0.0 + 0.5, 0.0), (0.2 * e + 0.5, lo), (0.2 * e, lo)),
+                _rect((0.0, e), (0.2 * e, hi), (0.2 * e + 0.5, hi), (0.0 + 0.5, e)),
+                _rect((e - 0.5, 0.0), (e, 0.0), (0.8 * e, lo), (0.8 * e - 0.5, lo)),
+                _rect((e - 0.5, e), (0.8 * e - 0.5, hi), (0.8 * e, hi), (e, e)),
+                _rect((0.2 * e, lo - 0.5), (0.8 * e, lo - 0.5), (0.8 * e, lo), (0.2 * e, lo)),
+                _rect((0.2 * e, hi + 0.5), (0.2 * e, hi), (0.8 * e, hi), (0.8 * e, hi + 0.5))]
     if scenario in ("crowd", SCN_CROWD):
         e = crowd_envsize(n_agents, radius)
         return [_rect((0.0, 0.0), (0.0, e), (e, e), (e, 0.0))]          # ALAN:291-292
@@ -54,7 +105,7 @@ def env_params():
 
 def alan_params(n_agents, scenario="crowd"):
     """The ALAN simulator's constants (ALAN:15-20, 47, 59)."""
-    e = crowd_envsize(n_agents) if scenario == "crowd" else circle_envsize(n_agents)
+    e = envsize(scenario, n_agents)
     return dict(time_step=1 / 60., neighbor_dist=5.0, max_neighbors=10, time_horizon=1.5,
                 time_horizon_obst=1.5, radius=0.5, max_speed=1.0,
                 max_step=int((10 / (1 / 60.)) * n_agents), done_mode=DONE_GOAL, done_x_thresh=2.0,

@@ -55,6 +55,10 @@ extern "C" {
 #define CA_SCN_CROWD 0   /* ALAN:270-294 random start / random goal                            */
 #define CA_SCN_CIRCLE 1  /* ALAN:297-330 circle swap                                           */
 #define CA_SCN_DOORWAY 2 /* env.py:77-123 the reference env's own world                        */
+#define CA_SCN_CONGESTED 3 /* ALAN:175-210 */
+#define CA_SCN_INCOMING 4  /* ALAN:213-267 */
+#define CA_SCN_BLOCKS 5    /* ALAN:333-374 (block obstacles come through ca_set_obstacles)       */
+#define CA_SCN_DEADLOCK 6  /* ALAN:377-457 */
 
 /* fields for ca_get / ca_set / ca_field_ptr */
 enum ca_field {

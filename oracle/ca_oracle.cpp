@@ -956,6 +956,47 @@ int orc_env_init_scenario(void* env, int32_t scenario) {
                 ar.pos[i] = mk((float)uniform64(E * 0.5, E, u0), (float)uniform64(0.0, E, u1));
                 e->goal_x[q] = 1.0f; e->goal_y[q] = 5.0f;
                 e->goal2_x[q] = -10.0f; e->goal2_y[q] = 5.0f; /* env.py:361 */
+            } else if (scenario >= 3 && scenario <= 6) { /* ALAN:175-193, 213-258, 333-357, 377-416 */
+                const double E = (scenario == 3) ? std::sqrt(2 * r * N) * 3
+                               : (scenario == 5) ? 3 * r * N : std::sqrt(2 * r * N) * 10;
+                double px = 0, py = 0, gx = 0, gy = 0, g2x = 0, g2y = 0;
+                if (scenario == 3) { /* congested */
+                    rng2(c.seed, g, i, RNG_POS, 0, &u0, &u1);
+                    px = uniform64(E * 0.2, E, u0); py = uniform64(0.0, E, u1);
+                    gx = 0.1 * E - 1.0; gy = E / 2; g2x = 0.1 * E - E; g2y = E / 2;
+                } else if (scenario == 4) { /* incoming */
+                    if (i == 0) {
+                        px = 0.1 * E; py = E / 2; gx = g2x = 0.9 * E; gy = g2y = E / 2;
+                    } else {
+                        const double len = std::sqrt((double)(N - 1)), x_inc = 3 * r, y_inc = 2.1 * r;
+                        const double y_start = E / 2 - ((y_inc * len) / 2);
+                        double x_pos = 0.8 * E, y_pos = y_start;
+                        for (int k = 1; k < i; ++k) { /* replay the placement loop up to this agent */
+                            y_pos += y_inc;
+                            if (y_pos > y_start + y_inc * len) { x_pos += x_inc; y_pos = y_start; }
+                        }
+                        px = x_pos; py = y_pos; gx = g2x = x_pos - 0.7 * E; gy = g2y = y_pos;
+                    }
+                } else if (scenario == 5) { /* blocks */
+                    double y_pos = 1.5 * r;
+                    for (int k = 0; k < i; ++k) y_pos += 3 * r;
+                    px = 1.5 * r; py = y_pos; gx = g2x = E - 1.5 * r; gy = g2y = y_pos;
+                } else { /* deadlock */
+                    const int half = N / 2;
+                    if (i < half) {
+                        double pos_x = 0.2 * E;
+                        for (int k = 0; k < i; ++k) pos_x += -3 * r;
+                        px = pos_x; gx = 0.9 * E; g2x = 0.9 * E + E;
+                    } else {
+                        double pos_x = 0.8 * E;
+                        for (int k = half; k < i; ++k) pos_x += 3 * r;
+                        px = pos_x; gx = 0.1 * E; g2x = 0.1 * E - E;
+                    }
+                    py = E / 2; gy = g2y = E / 2;
+                }
+                ar.pos[i] = mk((float)px, (float)py);
+                e->goal_x[q] = (float)gx; e->goal_y[q] = (float)gy;
+                e->goal2_x[q] = (float)g2x; e->goal2_y[q] = (float)g2y;
             } else {
                 return -1;
             }

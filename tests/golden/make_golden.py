@@ -265,17 +265,21 @@ def gen_alan_scenarios():
     warnings.simplefilter("ignore")
     import collision_avoidance.ALAN.ALAN_true as alan
     out = {}
-    for scen, n in (("circle", 8), ("circle", 100), ("crowd", 16)):
+    cases = (("circle", 8), ("circle", 100), ("crowd", 16), ("congested", 24), ("incoming", 17),
+             ("incoming", 26), ("blocks", 12), ("deadlock", 20), ("deadlock", 9))
+    for scen, n in cases:
         alan.uniform = _Stream(77)
         sim = alan.Collision_Avoidance_Sim(numAgents=n, scenario=scen, visualize=False)
-        pos = np.array([sim.sim.getAgentPosition(i) for i in range(n)], np.float32)
-        tgt = np.array([sim.world["targets_pos"][i][0] for i in range(n)], np.float64)
-        out["%s%d_pos" % (scen, n)] = pos
-        out["%s%d_goal" % (scen, n)] = tgt
-        out["%s%d_envsize" % (scen, n)] = np.float64(sim.envsize)
-        out["%s%d_max_step" % (scen, n)] = np.int32(sim.max_step)
+        key = "%s%d_" % (scen, n)
+        out[key + "pos"] = np.array([sim.sim.getAgentPosition(i) for i in range(n)], np.float32)
+        out[key + "goal"] = np.array([sim.world["targets_pos"][i][0] for i in range(n)], np.float64)
+        out[key + "goal2"] = np.array([sim.world["targets_pos"][i][1] for i in range(n)], np.float64)
+        out[key + "envsize"] = np.float64(sim.envsize)
+        out[key + "max_step"] = np.int32(sim.max_step)
+        out[key + "obst"] = np.array([[sim.sim.getObstacleVertex(v) for v in ids]
+                                      for ids in sim.world["obstacles_vertex_ids"]], np.float32)
     np.savez_compressed(os.path.join(HERE, "alan_scenarios.npz"), **out)
-    print("alan_scenarios.npz:", sorted(out))
+    print("alan_scenarios.npz:", len(out), "arrays for", [c[0] + str(c[1]) for c in cases])
 
 
 if __name__ == "__main__":

@@ -77,6 +77,11 @@ CASES = [
     ("k16", 3, 40, "crowd", dict(max_neighbors=16, neighbor_dist=6.0), 100, 50),
     ("k0", 3, 12, "crowd", dict(max_neighbors=0), 50, 25),
     ("single", 4, 1, "crowd", dict(), 50, 25),
+    # the other ALAN worlds: convex blocks, slanted funnels, a two-way tube, an incoming platoon
+    ("deadlock", 6, 20, "deadlock", dict(), 700, 100),
+    ("incoming", 6, 17, "incoming", dict(), 400, 100),
+    ("congested", 6, 24, "congested", dict(), 500, 100),
+    ("blocks", 6, 12, "blocks", dict(), 500, 100),
 ]
 
 

@@ -108,25 +108,45 @@ def test_env_loop_f32_close_to_reference(golden_dir, name):
 
 
 def test_alan_scenarios_match_reference(golden_dir):
+    """Start/goal layouts and obstacle polygons of every ALAN scenario against the reference's own
+    generators (ALAN_true.py:175-457); random draws (crowd/congested positions, block obstacles) are
+    checked for their boxes only."""
     g = np.load(os.path.join(golden_dir, "alan_scenarios.npz"))
-    for scen, n, sid in (("circle", 8, o.SCN_CIRCLE), ("circle", 100, o.SCN_CIRCLE)):
+    exact = (("circle", 8), ("circle", 100), ("incoming", 17), ("incoming", 26), ("blocks", 12),
+             ("deadlock", 20), ("deadlock", 9))
+    for scen, n in exact:
+        key = "%s%d_" % (scen, n)
         p = scenarios.alan_params(n, scen)
-        assert p["max_step"] == int(g["%s%d_max_step" % (scen, n)])
-        assert scenarios.circle_envsize(n) == float(g["%s%d_envsize" % (scen, n)])
+        assert p["max_step"] == int(g[key + "max_step"])
+        assert scenarios.envsize(scen, n) == float(g[key + "envsize"])
         env = o.OracleEnv(o.make_config(n_arenas=2, n_agents=n, **p))
-        env.init_scenario(sid)
+        env.init_scenario(scenarios.SCENARIO_IDS[scen])
         for a in range(2):
-            np.testing.assert_array_equal(env.get(o.FLD_POS_X)[a], g["%s%d_pos" % (scen, n)][:, 0])
-            np.testing.assert_array_equal(env.get(o.FLD_POS_Y)[a], g["%s%d_pos" % (scen, n)][:, 1])
-            np.testing.assert_array_equal(env.get(o.FLD_GOAL_X)[a],
-                                          g["%s%d_goal" % (scen, n)][:, 0].astype(np.float32))
-            np.testing.assert_array_equal(env.get(o.FLD_GOAL_Y)[a],
-                                          g["%s%d_goal" % (scen, n)][:, 1].astype(np.float32))
-    assert scenarios.crowd_envsize(16) == float(g["crowd16_envsize"])
-    # crowd positions are random in the reference; ours must lie in the same box
-    env = o.OracleEnv(o.make_config(n_arenas=3, n_agents=16, **scenarios.alan_params(16, "crowd")))
-    env.init_scenario(o.SCN_CROWD)
-    e = scenarios.crowd_envsize(16)
-    for f in (o.FLD_POS_X, o.FLD_POS_Y, o.FLD_GOAL_X, o.FLD_GOAL_Y):
-        v = env.get(f)
-        assert v.min() >= 0 and v.max() <= e
+            np.testing.assert_array_equal(env.get(o.FLD_POS_X)[a], g[key + "pos"][:, 0], err_msg=key)
+            np.testing.assert_array_equal(env.get(o.FLD_POS_Y)[a], g[key + "pos"][:, 1], err_msg=key)
+            for fx, fy, name in ((o.FLD_GOAL_X, o.FLD_GOAL_Y, "goal"), (o.FLD_GOAL2_X, o.FLD_GOAL2_Y, "goal2")):
+                np.testing.assert_array_equal(env.get(fx)[a], g[key + name][:, 0].astype(np.float32), err_msg=key + name)
+                np.testing.assert_array_equal(env.get(fy)[a], g[key + name][:, 1].astype(np.float32), err_msg=key + name)
+        if scen != "blocks":
+            polys = np.array(scenarios.obstacles(scen, n), np.float64).astype(np.float32)
+            np.testing.assert_array_equal(polys, g[key + "obst"], err_msg=key + "obst")
+    # random parts: same boxes as the reference's uniform() calls
+    for scen, n in (("crowd", 16), ("congested", 24)):
+        key = "%s%d_" % (scen, n)
+        e = scenarios.envsize(scen, n)
+        assert e == float(g[key + "envsize"])
+        env = o.OracleEnv(o.make_config(n_arenas=3, n_agents=n, **scenarios.alan_params(n, scen)))
+        env.init_scenario(scenarios.SCENARIO_IDS[scen])
+        x, y = env.get(o.FLD_POS_X), env.get(o.FLD_POS_Y)
+        x0 = 0.2 * e if scen == "congested" else 0.0
+        assert x.min() >= x0 and x.max() <= e and y.min() >= 0 and y.max() <= e
+        assert g[key + "pos"][:, 0].min() >= x0 - 1e-6
+        np.testing.assert_array_equal(np.array(scenarios.obstacles(scen, n), np.float64).astype(np.float32), g[key + "obst"])
+        if scen == "congested":
+            np.testing.assert_array_equal(env.get(o.FLD_GOAL_X)[0], g[key + "goal"][:, 0].astype(np.float32))
+            np.testing.assert_array_equal(env.get(o.FLD_GOAL2_X)[0], g[key + "goal2"][:, 0].astype(np.float32))
+    blk = np.array(scenarios.obstacles("blocks", 12, seed=5), np.float64)
+    e = scenarios.envsize("blocks", 12)
+    np.testing.assert_array_equal(blk[0].astype(np.float32), g["blocks12_obst"][0])      # the border
+    assert blk.shape == g["blocks12_obst"].shape and blk[1:].min() >= -e / 16 and blk[1:, :, 0].max() <= e
+    np.testing.assert_allclose(blk[1:, 1, 0] - blk[1:, 0, 0], e / 8)                      # block size
