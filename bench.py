@@ -80,11 +80,20 @@ def main():
     rank, world, local = cad.rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    # rehearsal switches (not used by the driver): CA_BENCH_BACKEND=gloo lets several ranks share one
+    # GPU on a 1-GPU box; the production path is one rank per GPU over RCCL ("nccl").
+    backend = os.environ.get("CA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     from collision_avoidance_amd import build as _b
     if rank == 0 and not os.path.exists(_b.LIB_PATH):  # normally prebuilt by __graft_entry__.build()
@@ -105,58 +114,59 @@ def main():
     pool = (torch.rand((16, A, N), device="cuda", generator=gen) - 0.5)  # actions in [-0.5, 0.5] rad
     full = args.mode == "step"
 
-    nev = 3 if full else 2
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(nev)] for _ in range(args.steps)]
-
-    def one_step(i, ev=None):
-        # the two launches of a full step, each bracketed by HIP events on the stream they run on
-        # (the handle runs on PyTorch's current stream)
-        if ev:
-            ev[0].record()
+    def one_step(i):  # the production call: one ca_step (neighbours -> ORCA solve -> observation)
         if full:
-            env._call("ca_step", env.h, pool[i % 16].data_ptr(), _lib.F_STATS)
-            if ev:
-                ev[1].record()
-            env._call("ca_observe", env.h)
-            if ev:
-                ev[2].record()
+            env._call("ca_step", env.h, pool[i % 16].data_ptr(), _lib.F_STATS | _lib.F_OBS)
         else:
             env._call("ca_orca_step", env.h, _lib.F_STATS)
-            if ev:
-                ev[1].record()
 
     for i in range(args.warmup):
         one_step(i)
+    # the kernel launches of every 8th step of the timed region are bracketed by HIP events on the
+    # stream they run on (recorded inside the library, which is where the launches are issued);
+    # sampling keeps the event records from stretching the timed region (every launch: +5 % wall)
+    env.profile(8)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        one_step(args.warmup + i, events[i])
+        one_step(args.warmup + i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    ktimes = env.profile_read()
+    env.profile(0)
     st = env.stats()
-    k_step = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))  # ms
-    k_obs = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if full else 0.0
 
     # the single collective of the job: per-rank statistics (RCCL all_gather over xGMI when N > 1)
-    per_rank_stats, total_stats = cad.gather_stats(st, device="cuda")
+    per_rank_stats, total_stats = cad.gather_stats(st, device=coll_dev)
     if rank == 0:
         agents = A * N
         value = world * agents * args.steps / dt
-        if full and k_obs >= k_step:
-            dom, kms, kbytes = "obs_kernel", k_obs, BYTES_OBS_KERNEL
-        else:
-            dom, kms, kbytes = "nbr_kernel+step_kernel", k_step, (BYTES_STEP_KERNEL_FULL if full else BYTES_STEP_KERNEL_ORCA)
+        kbytes_of = {"nbr_kernel": 0, "step_kernel": BYTES_STEP_KERNEL_FULL if full else BYTES_STEP_KERNEL_ORCA,
+                     "obs_kernel": BYTES_OBS_KERNEL}
+        kms_of = {k: v[1] for k, v in ktimes.items() if v[0] > 0 and k in kbytes_of}
+        dom = max(kms_of, key=kms_of.get)          # the kernel with the longest average launch
+        kms, kbytes = kms_of[dom], kbytes_of[dom]
+        if kbytes == 0:                              # nbr_kernel has no algorithmic HBM bytes of its own
+            dom = max((k for k in kms_of if kbytes_of[k] > 0), key=kms_of.get)
+            kms, kbytes = kms_of[dom], kbytes_of[dom]
         achieved = agents * kbytes / (kms * 1e-3) / 1e9
+        traffic = None
+        try:  # HBM bytes per launch from this round's committed rocprofv3 --pmc passes of this command
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_h_hbm_traffic_pmc.json")))
+            if args.workload == "C3" and full:
+                traffic = tj["kernels"][dom]["hbm_bytes_high"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "agent-steps/sec (whole node), %d arenas x %d agents per GPU" % (A, N),
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
@@ -169,10 +179,12 @@ def main():
                                     else "ORCA-only step (no observation)"),
                        "mode": args.mode, "sharding": "arenas, %d per GPU" % A},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_agent": kbytes, "kernel_ms": kms},
-            "kernels_ms": {"nbr_kernel+step_kernel": k_step, "obs_kernel": k_obs, "serial_sum": k_step + k_obs,
-                           "wall_per_step": dt / args.steps * 1e3},
+            "kernels_ms": dict({k: round(v, 5) for k, v in kms_of.items()}, sum=round(sum(kms_of.values()), 5),
+                               wall_per_step=dt / args.steps * 1e3),
+            "full_step_algorithmic": {"bytes_per_agent": 316 if full else 52,
+                                      "GB_per_s": agents * (316 if full else 52) / (dt / args.steps) / 1e9},
             "stats": {k: total_stats[k] for k in cad.STAT_KEYS},
             "launch": env.launch_info(),
         }

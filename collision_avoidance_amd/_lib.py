@@ -21,7 +21,7 @@ SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN
 
 EXPORTS = ("ca_create", "ca_destroy", "ca_last_error", "ca_set_stream", "ca_set_obstacles", "ca_init_scenario", "ca_set",
            "ca_get", "ca_field_ptr", "ca_bind_obs", "ca_reset", "ca_step", "ca_step_host", "ca_orca_step", "ca_observe", "ca_rollout",
-           "ca_get_stats", "ca_reset_stats", "ca_sync", "ca_debug_math", "ca_launch_info")
+           "ca_get_stats", "ca_reset_stats", "ca_sync", "ca_debug_math", "ca_profile", "ca_profile_read", "ca_launch_info")
 
 
 class Config(C.Structure):
@@ -88,6 +88,8 @@ def load():
     L.ca_reset_stats.argtypes = [vp]
     L.ca_sync.argtypes = [vp]
     L.ca_debug_math.argtypes = [vp, i32, vp, vp, i32]
+    L.ca_profile.argtypes = [vp, i32]
+    L.ca_profile_read.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_float)]
     L.ca_launch_info.argtypes = [vp] + [C.POINTER(i32)] * 4
     for name in EXPORTS:
         if name != "ca_last_error":

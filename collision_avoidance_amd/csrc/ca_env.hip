@@ -40,6 +40,12 @@ struct ca_env {
     size_t lds = 0;
     uint64_t steps_done = 0;  // env steps executed (agent_steps = steps_done * A * N)
     float rays[32], oct[32];
+    // opt-in per-kernel timing (ca_profile): event pairs recorded around launches, drained on read
+    bool profiling = false;   // events are recorded for the current step
+    int prof_period = 0;      // 0 = off, k = every k-th step
+    struct Span { hipEvent_t t0, t1; int kind; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> free_events;
     std::string err;
 };
 
@@ -60,6 +66,27 @@ static int fail(ca_env* e, int code, const char* fmt, ...) {
         hipError_t _r = (call);                                                                 \
         if (_r != hipSuccess) return fail(e, CA_EHIP, "%s failed: %s", #call, hipGetErrorString(_r)); \
     } while (0)
+
+enum { KIND_NBR = 0, KIND_STEP = 1, KIND_OBS = 2, KIND_RESET = 3 };
+static hipEvent_t prof_event(ca_env* e) {
+    if (!e->free_events.empty()) { hipEvent_t ev = e->free_events.back(); e->free_events.pop_back(); return ev; }
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return ev;
+}
+struct ProfScope {  // records an event before and after the launches issued while it is alive
+    ca_env* e; hipEvent_t t0 = nullptr; int kind;
+    ProfScope(ca_env* env, int k) : e(env), kind(k) {
+        if (e->profiling && (t0 = prof_event(e))) hipEventRecord(t0, e->stream);
+    }
+    ~ProfScope() {
+        if (!t0) return;
+        hipEvent_t t1 = prof_event(e);
+        if (!t1) { e->free_events.push_back(t0); return; }
+        hipEventRecord(t1, e->stream);
+        e->spans.push_back({t0, t1, kind});
+    }
+};
 
 static size_t AN(const ca_env* e) { return (size_t)e->cfg.n_arenas * e->cfg.n_agents; }
 
@@ -144,17 +171,20 @@ template <int KMAX>
 static hipError_t launch_step_k(ca_env* e, const StepArgs& a) {
     const dim3 grid(e->grid), block(e->BS);
     switch (e->BS) {  // neighbour search, then lines + LP + integration + reward/done on the same stream
-        case 64: hipLaunchKernelGGL((nbr_kernel<KMAX, 64>), grid, block, 0, e->stream, a);
-                 hipLaunchKernelGGL((step_kernel<KMAX, 64>), grid, block, e->lds, e->stream, a); break;
-        case 128: hipLaunchKernelGGL((nbr_kernel<KMAX, 128>), grid, block, 0, e->stream, a);
-                  hipLaunchKernelGGL((step_kernel<KMAX, 128>), grid, block, e->lds, e->stream, a); break;
-        case 256: hipLaunchKernelGGL((nbr_kernel<KMAX, 256>), grid, block, 0, e->stream, a);
-                  hipLaunchKernelGGL((step_kernel<KMAX, 256>), grid, block, e->lds, e->stream, a); break;
-        case 512: hipLaunchKernelGGL((nbr_kernel<KMAX, 512>), grid, block, 0, e->stream, a);
-                  hipLaunchKernelGGL((step_kernel<KMAX, 512>), grid, block, e->lds, e->stream, a); break;
-        default: hipLaunchKernelGGL((nbr_kernel<KMAX, 1024>), grid, block, 0, e->stream, a);
-                 hipLaunchKernelGGL((step_kernel<KMAX, 1024>), grid, block, e->lds, e->stream, a); break;
+#define CA_LAUNCH_PAIR(BSZ)                                                                          \
+    {                                                                                                \
+        { ProfScope ps(e, KIND_NBR);                                                                 \
+          hipLaunchKernelGGL((nbr_kernel<KMAX, BSZ>), grid, block, 0, e->stream, a); }               \
+        { ProfScope ps(e, KIND_STEP);                                                                \
+          hipLaunchKernelGGL((step_kernel<KMAX, BSZ>), grid, block, e->lds, e->stream, a); }         \
     }
+        case 64: CA_LAUNCH_PAIR(64) break;
+        case 128: CA_LAUNCH_PAIR(128) break;
+        case 256: CA_LAUNCH_PAIR(256) break;
+        case 512: CA_LAUNCH_PAIR(512) break;
+        default: CA_LAUNCH_PAIR(1024) break;
+    }
+#undef CA_LAUNCH_PAIR
     return hipGetLastError();
 }
 static hipError_t launch_step(ca_env* e, const StepArgs& a) {
@@ -201,6 +231,7 @@ static hipError_t launch_obs(ca_env* e) {
     memcpy(o.rays, e->rays, sizeof o.rays);
     memcpy(o.oct, e->oct, sizeof o.oct);
     const dim3 grid((unsigned)((size_t)o.A * o.bpa)), block(OBS_BS);
+    ProfScope ps(e, KIND_OBS);
     hipLaunchKernelGGL(obs_kernel, grid, block, obs_lds_bytes(o.N), e->stream, o);
     return hipGetLastError();
 }
@@ -303,6 +334,8 @@ int ca_destroy(ca_env* e) {
                     e->arena_done, e->episode, e->arena_stats, e->d_obst, e->dbg};
     for (void* b : bufs) if (b) hipFree(b);
     if (e->obs && !e->obs_external) hipFree(e->obs);
+    for (const ca_env::Span& sp : e->spans) { hipEventDestroy(sp.t0); hipEventDestroy(sp.t1); }
+    for (hipEvent_t ev : e->free_events) hipEventDestroy(ev);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
     delete e;
     return CA_OK;
@@ -524,9 +557,12 @@ int ca_reset(ca_env* e, const float* pos_x, const float* pos_y, int32_t pos_is_d
         }
     }
     const unsigned an = (unsigned)AN(e);
+    {
+    ProfScope ps(e, KIND_RESET);
     hipLaunchKernelGGL(reset_kernel, dim3((an + 255) / 256), dim3(256), 0, e->stream, a);
     HIPCHK(e, hipGetLastError());
     hipLaunchKernelGGL(reset_arena_kernel, dim3((e->cfg.n_arenas + 255) / 256), dim3(256), 0, e->stream, a);
+    }
     HIPCHK(e, hipGetLastError());
     e->orient_valid = true;
     if (flags & CA_F_OBS) HIPCHK(e, launch_obs(e));
@@ -534,6 +570,7 @@ int ca_reset(ca_env* e, const float* pos_x, const float* pos_y, int32_t pos_is_d
 }
 
 static int do_step(ca_env* e, const float* actions, uint32_t flags) {
+    if (e->prof_period > 1) e->profiling = (e->steps_done % (uint64_t)e->prof_period) == 0;
     StepArgs a;
     fill_args(e, a, actions, flags);
     HIPCHK(e, launch_step(e, a));
@@ -648,6 +685,30 @@ int ca_debug_stamps(ca_env* e, unsigned long long* out, int32_t max_waves, int32
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(out, e->dbg, (size_t)n * 16 * 8, hipMemcpyDeviceToHost));
+    return CA_OK;
+}
+
+int ca_profile(ca_env* e, int32_t period) {
+    if (!e || period < 0) return fail(e, CA_EINVAL, "ca_profile: bad argument");
+    e->prof_period = period;
+    e->profiling = period == 1;
+    return CA_OK;
+}
+
+int ca_profile_read(ca_env* e, int32_t counts[4], float mean_ms[4]) {
+    if (!e || !counts || !mean_ms) return fail(e, CA_EINVAL, "ca_profile_read: null argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    double sum[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k) counts[k] = 0;
+    for (const ca_env::Span& sp : e->spans) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, sp.t0, sp.t1) == hipSuccess) { sum[sp.kind] += ms; counts[sp.kind] += 1; }
+        e->free_events.push_back(sp.t0);
+        e->free_events.push_back(sp.t1);
+    }
+    e->spans.clear();
+    for (int k = 0; k < 4; ++k) mean_ms[k] = counts[k] ? (float)(sum[k] / counts[k]) : 0.0f;
     return CA_OK;
 }
 

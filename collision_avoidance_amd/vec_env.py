@@ -144,6 +144,17 @@ class VecCollisionAvoidanceEnv:
     def reset_stats(self):
         self._call("ca_reset_stats", self.h)
 
+    def profile(self, period=1):
+        """Bracket the kernel launches of every `period`-th step with HIP events (0 = off)."""
+        self._call("ca_profile", self.h, int(period))
+
+    def profile_read(self):
+        """{kernel: (launches, mean ms)} since the last read; synchronises."""
+        n = (C.c_int32 * 4)()
+        ms = (C.c_float * 4)()
+        self._call("ca_profile_read", self.h, n, ms)
+        return {k: (n[i], ms[i]) for i, k in enumerate(("nbr_kernel", "step_kernel", "obs_kernel", "reset_kernels"))}
+
     def launch_info(self):
         v = [C.c_int32() for _ in range(4)]
         self._call("ca_launch_info", self.h, *[C.byref(x) for x in v])
