@@ -33,6 +33,7 @@ struct ca_env {
     float* obs = nullptr;
     bool obs_external = false;
     unsigned long long* dbg = nullptr;  // CA_STAMPS diagnostic build only
+    unsigned long long* dbg_obs = nullptr;
     float *tmp_x = nullptr, *tmp_y = nullptr;  // staging for explicit reset positions / host actions
     ObstDev* d_obst = nullptr;
     std::vector<ObstDev> h_obst;
@@ -226,7 +227,7 @@ static hipError_t launch_obs(ca_env* e) {
     o.A = e->cfg.n_arenas; o.N = e->cfg.n_agents; o.S = e->S;
     o.K = e->K > 0 ? e->K : 1;  // nb_idx is allocated with one column when K == 0; counts are all zero
     o.bpa = (o.N + OBS_APB - 1) / OBS_APB;
-    o.a0 = 0;
+    o.a0 = 0; o.dbg = e->dbg_obs;
     o.radius = e->cfg.radius;
     memcpy(o.rays, e->rays, sizeof o.rays);
     memcpy(o.oct, e->oct, sizeof o.oct);
@@ -302,6 +303,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     if (r == hipSuccess) r = dalloc(&e->d_obst, (size_t)1);
 #ifdef CA_STAMPS
     if (r == hipSuccess) r = dalloc(&e->dbg, (size_t)e->grid * (e->BS / 64) * 16);
+    if (r == hipSuccess) r = dalloc(&e->dbg_obs, (size_t)cfg->n_arenas * ((cfg->n_agents + 15) / 16) * 4 * 16);
 #endif
     if (r == hipSuccess && e->lds > 48 * 1024) {
         if (e->K <= 5) r = set_lds_attr_k<5>(e->BS, e->lds);
@@ -331,7 +333,7 @@ int ca_destroy(ca_env* e) {
                     e->goal2_x, e->goal2_y, e->reward, e->tmp_x, e->tmp_y, e->orient_x, e->orient_y,
                     e->agent_done, e->arrive_step,
                     e->regoal_count, e->nb_count, e->nb_idx, e->obst_count, e->obst_idx, e->step_count,
-                    e->arena_done, e->episode, e->arena_stats, e->d_obst, e->dbg};
+                    e->arena_done, e->episode, e->arena_stats, e->d_obst, e->dbg, e->dbg_obs};
     for (void* b : bufs) if (b) hipFree(b);
     if (e->obs && !e->obs_external) hipFree(e->obs);
     for (const ca_env::Span& sp : e->spans) { hipEventDestroy(sp.t0); hipEventDestroy(sp.t1); }
@@ -679,12 +681,14 @@ int ca_debug_math(ca_env* e, int32_t op, const void* in, void* out, int32_t n) {
  * of the last step kernel, [waves][16] u64. */
 int ca_debug_stamps(ca_env* e, unsigned long long* out, int32_t max_waves, int32_t* n_waves) {
     if (!e || !e->dbg) return fail(e, CA_EINVAL, "ca_debug_stamps: not a CA_STAMPS build");
-    const int nw = e->grid * (e->BS / 64);
+    const bool obs = max_waves < 0;  // negative: the observation kernel's stamps
+    if (obs) max_waves = -max_waves;
+    const int nw = obs ? e->cfg.n_arenas * ((e->cfg.n_agents + 15) / 16) * 4 : e->grid * (e->BS / 64);
     if (n_waves) *n_waves = nw;
     const int n = nw < max_waves ? nw : max_waves;
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    HIPCHK(e, hipMemcpy(out, e->dbg, (size_t)n * 16 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(out, obs ? e->dbg_obs : e->dbg, (size_t)n * 16 * 8, hipMemcpyDeviceToHost));
     return CA_OK;
 }
 

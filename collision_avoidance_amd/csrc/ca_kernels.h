@@ -141,16 +141,28 @@ __device__ __forceinline__ int lp2(const LS& ls, int n, float radius, V2 opt, bo
     return n;
 }
 
-// App. A.5 LP3 (rare: only when LP2 is infeasible).  The projected lines live in private memory.
+// App. A.5 LP3: only for lanes whose LP2 was infeasible -- which in a dense crowd is ~9 % of the
+// agent-steps, i.e. a few lanes of EVERY wave.  The projected lines go to a second LDS table
+// (CA_LP3_LDS, rows [K+S, 2(K+S)) of the line table) or to private memory.
+#ifndef CA_LP3_LDS
+#define CA_LP3_LDS 0
+#endif
 template <int MAXL>
-__device__ __noinline__ void lp3(LdsLines ls, int n, int numObst, int begin, float radius, V2& result) {
+__device__ __noinline__ void lp3(LdsLines ls, LdsLines pj, int n, int numObst, int begin, float radius, V2& result) {
+#if !CA_LP3_LDS
     Line proj[MAXL];
+#endif
     float distance = 0.0f;
     for (int i = begin; i < n; ++i) {
         const Line Li = ls.get(i);
         if (det(Li.dir, Li.point - result) > distance) {
             int m = 0;
-            for (int j = 0; j < numObst; ++j) proj[m++] = ls.get(j);
+#if CA_LP3_LDS
+#define CA_PROJ_PUT(l) pj.put(m++, l)
+#else
+#define CA_PROJ_PUT(l) proj[m++] = l
+#endif
+            for (int j = 0; j < numObst; ++j) { const Line l0 = ls.get(j); CA_PROJ_PUT(l0); }
             for (int j = numObst; j < i; ++j) {
                 const Line Lj = ls.get(j);
                 Line l;
@@ -162,11 +174,16 @@ __device__ __noinline__ void lp3(LdsLines ls, int n, int numObst, int begin, flo
                     l.point = Li.point + (det(Lj.dir, Li.point - Lj.point) / d) * Li.dir;
                 }
                 l.dir = normalize(Lj.dir - Li.dir);
-                proj[m++] = l;
+                CA_PROJ_PUT(l);
             }
+#undef CA_PROJ_PUT
             const V2 tmp = result;
+#if CA_LP3_LDS
+            if (lp2(pj, m, radius, mk(-Li.dir.y, Li.dir.x), true, result) < m) result = tmp;
+#else
             PrivLines pl; pl.p = proj;
             if (lp2(pl, m, radius, mk(-Li.dir.y, Li.dir.x), true, result) < m) result = tmp;
+#endif
             distance = det(Li.dir, Li.point - result);
         }
     }
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
 
 // LDS carve-up of the step kernel (bytes): lines | px py vx vy | misc ints
 __host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S) {
-    return (size_t)BS * ((size_t)(K + S) * 16 + 16 + 16);
+    return (size_t)BS * ((size_t)(K + S) * 16 * (CA_LP3_LDS ? 2 : 1) + 16 + 16);
 }
 
 // ============================================================================================
@@ -499,7 +516,7 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     const int lbase = la << p.logP;
 
     float4* s_lines = smem4;                                   // [(K+S)][BS]
-    float* s_px = reinterpret_cast<float*>(smem4 + (size_t)(K + S) * BS);
+    float* s_px = reinterpret_cast<float*>(smem4 + (size_t)(K + S) * BS * (CA_LP3_LDS ? 2 : 1));
     float* s_py = s_px + BS;
     float* s_vx = s_py + BS;
     float* s_vy = s_vx + BS;
@@ -579,7 +596,10 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     if (active) fail = lp2(ls, nl, p.max_speed, pref, false, nv);
     CA_STAMP(6);
     if (active) {
-        if (fail < nl) lp3<KMAX + SMAX>(ls, nl, numObstLines, fail, p.max_speed, nv);
+        if (fail < nl) {
+            LdsLines pj; pj.base = ls.base + (size_t)(K + S) * BS; pj.stride = BS;
+            lp3<KMAX + SMAX>(ls, pj, nl, numObstLines, fail, p.max_speed, nv);
+        }
         // ---- integrate (App. A.1) ----
         vel = nv;
         pos = pos + vel * p.time_step;
@@ -766,7 +786,7 @@ __global__ void reset_arena_kernel(const StepArgs p) {  // after reset_kernel: p
 //
 // A workgroup (256 lanes) owns 16 agents of ONE arena; 16 lanes per agent.  The arena's
 // positions/velocities are staged in LDS once (the neighbour gathers then never leave the CU).
-// Phase A -- lane per SEGMENT: the 16 lanes of an agent walk its segment list (8 octagon chords
+// Phase A -- lane per (source, ray, SEGMENT) task: the 16 lanes of an agent walk the tasks (8 octagon chords
 //   per ORCA agent neighbour, one segment per ORCA obstacle neighbour), rotate each segment into
 //   the goal-aligned frame and test it only against the rays that can possibly reach it: the
 //   rays inside the segment's angular span as seen from the origin (a conservative superset, see
@@ -784,18 +804,43 @@ struct ObsArgs {
     float* obs;
     int A, N, K, S, bpa;  // bpa = workgroups per arena = ceil(N / 16)
     int a0;               // first arena of this launch
+    unsigned long long* dbg;  // CA_STAMPS diagnostic build only: [waves][16] phase time stamps
     float radius;         // of the octagon = agent radius (env.py:31,338)
     float rays[32];       // env.py:321-332
     float oct[32];        // env.py:335-350
 };
 
+#ifdef CA_STAMPS
+#define CA_OSTAMP(k)                                                                       \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();                        \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                \
+        if ((threadIdx.x & 63) == 0 && p.dbg)                                              \
+            p.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = _t;          \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+#else
+#define CA_OSTAMP(k) do { } while (0)
+#endif
+// Orders the LDS traffic of ONE wave: LDS executes a wave's instructions in issue order, so lanes of
+// the same wave only need the compiler not to move accesses across this point and the earlier
+// operations to have been issued and returned (s_waitcnt lgkmcnt(0)).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 constexpr int OBS_BS = 256;
 constexpr int OBS_APB = OBS_BS / 16;  // agents per workgroup
+constexpr int OBS_PAIRCAP = 16 * (16 + 8);  // (source, ray) pairs of one agent: <= 16 rays x (K + S) sources
 
 // LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | nb idx [16][16] | obstacle idx [16][8]
-//              | ray and octagon tables [64] | per-neighbour ray windows [16][16]
+//              | ray and octagon tables [64] | pair counts [16] | (source, ray) pair lists [16][384] u16
 __host__ __device__ inline size_t obs_lds_bytes(int N) {
-    return (size_t)N * 16 + OBS_APB * 16 * 8 + OBS_APB * 16 * 4 + OBS_APB * 8 * 4 + 64 * 4 + OBS_APB * 16 * 4;
+    return (size_t)N * 16 + OBS_APB * 16 * 8 + OBS_APB * 16 * 4 + OBS_APB * 8 * 4 + 64 * 4 + OBS_APB * 4 +
+           (size_t)OBS_APB * OBS_PAIRCAP * 2;
 }
 
 struct SegGeom {  // one segment in the goal-aligned frame, in the reference's intermediate terms
@@ -860,7 +905,9 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     int* s_ob = s_nb + OBS_APB * 16;
     float* s_rays = reinterpret_cast<float*>(s_ob + OBS_APB * 8);  // [32] rays then [32] octagon
     float* s_oct = s_rays + 32;
-    int* s_win = reinterpret_cast<int*>(s_oct + 32);
+    int* s_cnt = reinterpret_cast<int*>(s_oct + 32);                       // [16] pairs per agent
+    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_cnt + OBS_APB);  // [16][OBS_PAIRCAP]
+    CA_OSTAMP(0);
     if (tid < 32) { s_rays[tid] = p.rays[tid]; s_oct[tid] = p.oct[tid]; }
 
     for (int t = tid; t < N; t += OBS_BS) {
@@ -876,26 +923,63 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         if (r < ns) s_ob[g * 8 + r] = p.obst_idx[((size_t)a * S + r) * N + i];
     }
     s_key[g * 16 + r] = ~0ull;
+    if (r == 0) s_cnt[g] = 0;
+    CA_OSTAMP(1);
     __syncthreads();
+    CA_OSTAMP(2);
 
     const int M = 8 * nn + ns;
     float mx = 0.0f, my = 0.0f;
     if (M > 0) { mx = s_px[i]; my = s_py[i]; }
-    // ---- pre-pass, lane per NEIGHBOUR: the rays that can reach its octagon.  All 8 vertices lie on
-    // the circle of radius R around the neighbour, so the rays within asin(R/d) of its direction
-    // are a superset for each of its 8 chords (margin 0.02 dial units = 7.8e-3 rad, see ray_span).
-    for (int k = r; k < nn; k += 16) {
-        const int nb = s_nb[g * 16 + k];
-        const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
-        const float d2 = rx * rx + ry * ry, R = p.radius;
-        const float u = ray_dial(c * rx - s * ry, s * rx + c * ry);
-        const float h = ray_dial(__builtin_amdgcn_sqrtf(fmaxf(d2 - R * R, 0.0f)), -R);  // atan2(R, sqrt(d2-R2))
-        const bool all = !(d2 > 1.0404f * R * R);  // the agent is inside (or within 2 % of) that circle
-        int i0 = (int)ceilf(u - h - 0.02f), i1 = (int)floorf(u + h + 0.02f);
+    // ---- pre-pass, lane per NEIGHBOUR / OBSTACLE EDGE: the rays that can reach it ("ray window").
+    // Agent neighbour: all 8 octagon vertices lie on the circle of radius R around it, so the rays
+    // within asin(R/d) of its direction are a superset for each of its 8 chords (margin 0.02 dial
+    // units = 7.8e-3 rad).  Obstacle edge: the angular span of its two end points (see ray_span).
+    // Both cases evaluate the dial of two points, so the lanes share one instruction stream.
+    for (int k = r; k < nn + ns; k += 16) {
+        float ax, ay, bx, by;
+        bool all;
+        const bool is_nb = k < nn;
+        if (is_nb) {
+            const int nb = s_nb[g * 16 + k];
+            const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
+            const float d2 = rx * rx + ry * ry, R = p.radius;
+            ax = c * rx - s * ry; ay = s * rx + c * ry;
+            bx = __builtin_amdgcn_sqrtf(fmaxf(d2 - R * R, 0.0f)); by = -R;  // dial(b) = atan2(R, sqrt(d2-R2))
+            all = !(d2 > 1.0404f * R * R);  // the agent is inside (or within 2 % of) that circle
+        } else {
+            const ObstDev o1 = load_obst(p.obst, s_ob[g * 8 + (k - nn)]);
+            const float x1 = o1.px - mx, y1 = o1.py - my, x2 = o1.qx - mx, y2 = o1.qy - my;
+            ax = c * x1 - s * y1; ay = s * x1 + c * y1;
+            bx = c * x2 - s * y2; by = s * x2 + c * y2;
+            const float n2 = ax * ax + ay * ay, n3 = bx * bx + by * by;
+            all = !(fminf(n2, n3) > 1e-6f * fmaxf(n2, n3)) || !(fminf(n2, n3) > 1e-12f);
+        }
+        const float ua = ray_dial(ax, ay), ub = ray_dial(bx, by);
+        float lo, hi;
+        if (is_nb) {
+            lo = ua - ub - 0.02f; hi = ua + ub + 0.02f;
+        } else {
+            float du = ub - ua;
+            du = (du > 8.0f) ? du - 16.0f : du;
+            du = (du <= -8.0f) ? du + 16.0f : du;
+            all = all || (fabsf(du) > 7.8f);
+            lo = ua + fminf(du, 0.0f) - 0.01f; hi = ua + fmaxf(du, 0.0f) + 0.01f;
+        }
+        int i0 = (int)ceilf(lo), i1 = (int)floorf(hi);
         if (all || i1 - i0 >= 15) { i0 = 0; i1 = 15; }
-        s_win[g * 16 + k] = (i0 + 64) | ((i1 + 64) << 16);
+        // emit one (source, ray) pair per ray of the window (the list order is irrelevant: results are
+        // merged with a commutative minimum)
+        const int w = i1 - i0 + 1;
+        if (w > 0) {
+            const int base = atomicAdd(&s_cnt[g], w);
+            for (int t = 0; t < w; ++t)
+                s_pair[g * OBS_PAIRCAP + base + t] = (unsigned short)((k << 4) | ((i0 + t) & 15));
+        }
     }
-    __syncthreads();
+    CA_OSTAMP(3);
+    wave_lds_sync();  // the 16 lanes of an agent are in one wave: no workgroup barrier needed
+    CA_OSTAMP(4);
     // segment m of this agent in the rotated frame (env.py:283-294, 305-315; utils.py:55-62)
     auto build = [&](int m, SegGeom& sg, float& velx, float& vely, bool want_vel) {
         float x1, y1, x2, y2, vx = 0.0f, vy = 0.0f;
@@ -923,7 +1007,9 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             velx = rvx - sg.r1x; vely = rvy - sg.r1y;                      // utils.py:62
         }
     };
-    // utils.py:5-40 for the ray with end point (s10x, s10y) starting at the origin
+    // utils.py:5-40 for the ray with end point (s10x, s10y) starting at the origin.  (Deferring the
+    // division/sqrt/atomic of accepted pairs to a second loop over a hit bitmask, and a branch-free
+    // accept test, were both measured SLOWER: 136-138 us vs 117 us at C3.)
     auto hit = [&](const SegGeom& sg, float s10x, float s10y, float& d, float& hx, float& hy) -> bool {
         const float denom = s10x * sg.s32y - sg.s32x * s10y;          // utils.py:14
         if (denom == 0.0f) return false;
@@ -938,28 +1024,24 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         return true;
     };
 
-    // ---- phase A: lane per segment ----
-    for (int m = r; m < M; m += 16) {
+    // ---- phase A: lane per (source, ray, segment) task: 8 tasks per pair (an obstacle edge uses one) ----
+    const int ntask = 8 * s_cnt[g];
+    for (int tk = r; tk < ntask; tk += 16) {
+        const int pr = s_pair[g * OBS_PAIRCAP + (tk >> 3)];
+        const int k = pr >> 4, ray = pr & 15, e = tk & 7;
+        if (k >= nn && e != 0) continue;
+        const int m = (k < nn) ? 8 * k + e : 8 * nn + (k - nn);
         SegGeom sg;
-        float dum0, dum1;
+        float dum0, dum1, d, hx, hy;
         build(m, sg, dum0, dum1, false);
-        int i0, i1;
-        if (m < 8 * nn) {
-            const int w = s_win[g * 16 + (m >> 3)];
-            i0 = (w & 0xffff) - 64; i1 = (w >> 16) - 64;
-        } else {
-            ray_span(sg.r1x, sg.r1y, sg.r2x, sg.r2y, &i0, &i1);
-        }
-        for (int ii = i0; ii <= i1; ++ii) {
-            const int ray = ii & 15;
-            float d, hx, hy;
-            if (hit(sg, s_rays[2 * ray] - 0.0f, s_rays[2 * ray + 1] - 0.0f, d, hx, hy)) {
-                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)m;
-                atomicMin(&s_key[g * 16 + ray], key);
-            }
+        if (hit(sg, s_rays[2 * ray] - 0.0f, s_rays[2 * ray + 1] - 0.0f, d, hx, hy)) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)m;
+            atomicMin(&s_key[g * 16 + ray], key);
         }
     }
-    __syncthreads();
+    CA_OSTAMP(5);
+    wave_lds_sync();
+    CA_OSTAMP(6);
     if (!active) return;
     // ---- phase B: lane per ray ----
     const unsigned long long key = s_key[g * 16 + r];
@@ -971,7 +1053,9 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         hit(sg, s_rays[2 * r] - 0.0f, s_rays[2 * r + 1] - 0.0f, d, bx, by);
         if (!(bx == 0.0f && by == 0.0f)) { vx = wx; vy = wy; }  // utils.py:103
     }
+    CA_OSTAMP(7);
     reinterpret_cast<float4*>(p.obs)[q * 16 + r] = make_float4(bx, by, vx, vy);
+    CA_OSTAMP(8);
 }
 
 // ---- diagnostics for the numerics contract ----

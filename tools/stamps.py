@@ -42,6 +42,19 @@ for s in range(120):
         env._call("ca_debug_stamps", env.h, buf.ctypes.data, buf.shape[0], C.byref(nw))
         t = buf[:nw.value, :12].astype(np.int64)
         acc.append(np.diff(t, axis=1))
+# the observation kernel of the last step
+nw = C.c_int32()
+obuf = np.zeros((A * ((N + 15) // 16) * 4, 16), np.uint64)
+if mode == "step":
+    env.observe()
+    env._call("ca_debug_stamps", env.h, obuf.ctypes.data, -obuf.shape[0], C.byref(nw))
+    to = np.diff(obuf[:nw.value, :9].astype(np.int64), axis=1)
+    to = to[(obuf[:nw.value, 8] > 0)]
+    onames = ["stage arena+lists", "barrier", "pre-pass (windows, pairs)", "barrier", "phase A (tasks)", "barrier",
+              "phase B (winner)", "store"]
+    print("obs_kernel: %d waves, mean cycles/wave %.0f" % (len(to), to.sum(axis=1).mean()))
+    for k, n in enumerate(onames):
+        print("  %-26s %8.0f cycles  %5.1f %%" % (n, to[:, k].mean(), 100 * to[:, k].mean() / to.sum(axis=1).mean()))
 d = np.concatenate(acc)
 tot = d.sum(axis=1)
 print("%s %s: %d waves sampled, mean cycles/wave %.0f (p50 %.0f, p95 %.0f)" %
