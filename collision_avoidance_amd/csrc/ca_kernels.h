@@ -786,7 +786,7 @@ __global__ void reset_arena_kernel(const StepArgs p) {  // after reset_kernel: p
 //
 // A workgroup (256 lanes) owns 16 agents of ONE arena; 16 lanes per agent.  The arena's
 // positions/velocities are staged in LDS once (the neighbour gathers then never leave the CU).
-// Phase A -- lane per (source, ray, SEGMENT) task: the 16 lanes of an agent walk the tasks (8 octagon chords
+// Phase A -- lane per (source, ray) pair: the 16 lanes of an agent walk the pairs (8 octagon chords
 //   per ORCA agent neighbour, one segment per ORCA obstacle neighbour), rotate each segment into
 //   the goal-aligned frame and test it only against the rays that can possibly reach it: the
 //   rays inside the segment's angular span as seen from the origin (a conservative superset, see
@@ -1024,18 +1024,56 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         return true;
     };
 
-    // ---- phase A: lane per (source, ray, segment) task: 8 tasks per pair (an obstacle edge uses one) ----
-    const int ntask = 8 * s_cnt[g];
-    for (int tk = r; tk < ntask; tk += 16) {
-        const int pr = s_pair[g * OBS_PAIRCAP + (tk >> 3)];
-        const int k = pr >> 4, ray = pr & 15, e = tk & 7;
-        if (k >= nn && e != 0) continue;
-        const int m = (k < nn) ? 8 * k + e : 8 * nn + (k - nn);
+    // ---- phase A: lane per (source, ray) pair ----
+    // An agent neighbour contributes the 8 chords of its octagon; consecutive chords share an end point
+    // bit for bit (env.py:335-350 builds them as a chain), so the 8 rotated vertices are computed once
+    // per pair and every chord is accept-tested against the pair's single ray.  Only accepted chords
+    // (about two per pair) are re-derived through build()/hit() for the exact hit distance.
+    const int np = s_cnt[g];
+    for (int pi = r; pi < np; pi += 16) {
+        const int pr = s_pair[g * OBS_PAIRCAP + pi];
+        const int k = pr >> 4, ray = pr & 15;
+        const float s10x = s_rays[2 * ray] - 0.0f, s10y = s_rays[2 * ray + 1] - 0.0f;
+        float best = __int_as_float(0x7f800000);
+        int best_m = -1;
         SegGeom sg;
         float dum0, dum1, d, hx, hy;
-        build(m, sg, dum0, dum1, false);
-        if (hit(sg, s_rays[2 * ray] - 0.0f, s_rays[2 * ray + 1] - 0.0f, d, hx, hy)) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)m;
+        if (k < nn) {
+            const int nb = s_nb[g * 16 + k];
+            const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
+            float vx[8], vy[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
+                const float x1 = oc.x + rx, y1 = oc.y + ry;
+                vx[e] = c * x1 - s * y1; vy[e] = s * x1 + c * y1;      // utils.py:59 (= utils.py:60 of chord e-1)
+            }
+            unsigned acc = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float r1x = vx[e], r1y = vy[e], r2x = vx[(e + 1) & 7], r2y = vy[(e + 1) & 7];
+                const float s32x = r2x - r1x, s32y = r2y - r1y, s02x = 0.0f - r1x, s02y = 0.0f - r1y;
+                const float t_numer = s32x * s02y - s32y * s02x;
+                const float denom = s10x * s32y - s32x * s10y;            // utils.py:14
+                const float s_numer = s10x * s02y - s10y * s02x;          // utils.py:21
+                const bool dpos = denom > 0.0f;
+                const bool ok = (denom != 0.0f) && ((s_numer < 0.0f) != dpos) && ((t_numer < 0.0f) != dpos) &&
+                                ((s_numer > denom) != dpos) && ((t_numer > denom) != dpos);  // utils.py:15-31
+                acc |= ok ? (1u << e) : 0u;
+            }
+            while (acc) {  // ascending chord index, strict '<': the first minimum wins
+                const int e = __ffs(acc) - 1;
+                acc &= acc - 1;
+                build(8 * k + e, sg, dum0, dum1, false);
+                if (hit(sg, s10x, s10y, d, hx, hy) && d < best) { best = d; best_m = 8 * k + e; }
+            }
+        } else {
+            const int m = 8 * nn + (k - nn);
+            build(m, sg, dum0, dum1, false);
+            if (hit(sg, s10x, s10y, d, hx, hy)) { best = d; best_m = m; }
+        }
+        if (best_m >= 0) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)best_m;
             atomicMin(&s_key[g * 16 + ray], key);
         }
     }
