@@ -142,27 +142,18 @@ __device__ __forceinline__ int lp2(const LS& ls, int n, float radius, V2 opt, bo
 }
 
 // App. A.5 LP3: only for lanes whose LP2 was infeasible -- which in a dense crowd is ~9 % of the
-// agent-steps, i.e. a few lanes of EVERY wave.  The projected lines go to a second LDS table
-// (CA_LP3_LDS, rows [K+S, 2(K+S)) of the line table) or to private memory.
-#ifndef CA_LP3_LDS
-#define CA_LP3_LDS 0
-#endif
+// agent-steps, i.e. a few lanes of EVERY wave.  The projected lines live in private memory: a second
+// LDS table for them halves the occupancy of this LDS-bound kernel and was measured slower
+// (profiles/r01_k_lp3_lds_negative_result.txt).
 template <int MAXL>
-__device__ __noinline__ void lp3(LdsLines ls, LdsLines pj, int n, int numObst, int begin, float radius, V2& result) {
-#if !CA_LP3_LDS
+__device__ __noinline__ void lp3(LdsLines ls, int n, int numObst, int begin, float radius, V2& result) {
     Line proj[MAXL];
-#endif
     float distance = 0.0f;
     for (int i = begin; i < n; ++i) {
         const Line Li = ls.get(i);
         if (det(Li.dir, Li.point - result) > distance) {
             int m = 0;
-#if CA_LP3_LDS
-#define CA_PROJ_PUT(l) pj.put(m++, l)
-#else
-#define CA_PROJ_PUT(l) proj[m++] = l
-#endif
-            for (int j = 0; j < numObst; ++j) { const Line l0 = ls.get(j); CA_PROJ_PUT(l0); }
+            for (int j = 0; j < numObst; ++j) proj[m++] = ls.get(j);
             for (int j = numObst; j < i; ++j) {
                 const Line Lj = ls.get(j);
                 Line l;
@@ -174,16 +165,11 @@ __device__ __noinline__ void lp3(LdsLines ls, LdsLines pj, int n, int numObst, i
                     l.point = Li.point + (det(Lj.dir, Li.point - Lj.point) / d) * Li.dir;
                 }
                 l.dir = normalize(Lj.dir - Li.dir);
-                CA_PROJ_PUT(l);
+                proj[m++] = l;
             }
-#undef CA_PROJ_PUT
             const V2 tmp = result;
-#if CA_LP3_LDS
-            if (lp2(pj, m, radius, mk(-Li.dir.y, Li.dir.x), true, result) < m) result = tmp;
-#else
             PrivLines pl; pl.p = proj;
             if (lp2(pl, m, radius, mk(-Li.dir.y, Li.dir.x), true, result) < m) result = tmp;
-#endif
             distance = det(Li.dir, Li.point - result);
         }
     }
@@ -385,13 +371,6 @@ __device__ __forceinline__ void sorted_insert(double (&key)[MAXN], double x) {
     for (int k = MAXN - 1; k >= 1; --k) key[k] = key_max(key[k - 1], key_min(key[k], x));
     key[0] = key_min(key[0], x);
 }
-template <int MAXN>
-__device__ __forceinline__ int pick(const int (&v)[MAXN], int k) {
-    int r = v[0];
-#pragma unroll
-    for (int j = 1; j < MAXN; ++j) r = (k == j) ? v[j] : r;
-    return r;
-}
 // ============================================================================================
 // Neighbour search for every agent (App. A.2): the obstacle edges within range and
 // the K nearest agents, written as the lists [A,S,N] / [A,K,N] that the solve kernel and the
@@ -479,7 +458,7 @@ __global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
 
 // LDS carve-up of the step kernel (bytes): lines | px py vx vy | misc ints
 __host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S) {
-    return (size_t)BS * ((size_t)(K + S) * 16 * (CA_LP3_LDS ? 2 : 1) + 16 + 16);
+    return (size_t)BS * ((size_t)(K + S) * 16 + 16 + 16);
 }
 
 // ============================================================================================
@@ -516,7 +495,7 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     const int lbase = la << p.logP;
 
     float4* s_lines = smem4;                                   // [(K+S)][BS]
-    float* s_px = reinterpret_cast<float*>(smem4 + (size_t)(K + S) * BS * (CA_LP3_LDS ? 2 : 1));
+    float* s_px = reinterpret_cast<float*>(smem4 + (size_t)(K + S) * BS);
     float* s_py = s_px + BS;
     float* s_vx = s_py + BS;
     float* s_vy = s_vx + BS;
@@ -596,10 +575,7 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     if (active) fail = lp2(ls, nl, p.max_speed, pref, false, nv);
     CA_STAMP(6);
     if (active) {
-        if (fail < nl) {
-            LdsLines pj; pj.base = ls.base + (size_t)(K + S) * BS; pj.stride = BS;
-            lp3<KMAX + SMAX>(ls, pj, nl, numObstLines, fail, p.max_speed, nv);
-        }
+        if (fail < nl) lp3<KMAX + SMAX>(ls, nl, numObstLines, fail, p.max_speed, nv);
         // ---- integrate (App. A.1) ----
         vel = nv;
         pos = pos + vel * p.time_step;
@@ -867,24 +843,13 @@ __device__ __forceinline__ float ray_dial(float x, float y) {
     return (u < 0.0f) ? u + 16.0f : u;
 }
 
-// Candidate rays [i0, i1] (take & 15) for a segment with end points p2, p3: every ray the exact
-// test could accept lies inside.  The exact test accepts a ray only if its direction is between
-// the directions of p2 and p3 (short way round) up to fp32 rounding of two cross products, i.e.
-// up to ~1e-7 rad unless an end point is very close to the origin compared with the other;
-// the dial error is < 1e-4 and the margin is 0.01 dial units (3.9e-3 rad).  Segments passing
-// (almost) through the origin, where "short way round" is ill-defined, get all 16 rays.
-__device__ __forceinline__ void ray_span(float p2x, float p2y, float p3x, float p3y, int* i0, int* i1) {
-    const float n2 = p2x * p2x + p2y * p2y, n3 = p3x * p3x + p3y * p3y;
-    const float u2 = ray_dial(p2x, p2y), u3 = ray_dial(p3x, p3y);
-    float du = u3 - u2;
-    du = (du > 8.0f) ? du - 16.0f : du;
-    du = (du <= -8.0f) ? du + 16.0f : du;
-    const bool all = (fabsf(du) > 7.8f) || !(fminf(n2, n3) > 1e-6f * fmaxf(n2, n3)) || !(fminf(n2, n3) > 1e-12f);
-    const float lo = u2 + fminf(du, 0.0f) - 0.01f, hi = u2 + fmaxf(du, 0.0f) + 0.01f;
-    *i0 = all ? 0 : (int)ceilf(lo);
-    *i1 = all ? 15 : (int)floorf(hi);
-}
-
+// Ray windows.  For a SEGMENT with end points p2, p3 every ray the exact test could accept lies in
+// the angular span between the directions of p2 and p3 (short way round): the test accepts a ray
+// only if its direction is between them up to fp32 rounding of two cross products, i.e. up to
+// ~1e-7 rad unless an end point is very close to the origin compared with the other; the dial error
+// is < 1e-4 and the margin is 0.01 dial units (3.9e-3 rad).  Segments passing (almost) through the
+// origin, where "short way round" is ill-defined, get all 16 rays.  For an agent NEIGHBOUR the
+// window is that of the circle through its octagon's vertices (see the pre-pass).
 __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     extern __shared__ float4 smem4[];
     const int tid = threadIdx.x;
@@ -934,7 +899,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     // ---- pre-pass, lane per NEIGHBOUR / OBSTACLE EDGE: the rays that can reach it ("ray window").
     // Agent neighbour: all 8 octagon vertices lie on the circle of radius R around it, so the rays
     // within asin(R/d) of its direction are a superset for each of its 8 chords (margin 0.02 dial
-    // units = 7.8e-3 rad).  Obstacle edge: the angular span of its two end points (see ray_span).
+    // units = 7.8e-3 rad).  Obstacle edge: the angular span of its two end points (see "Ray windows").
     // Both cases evaluate the dial of two points, so the lanes share one instruction stream.
     for (int k = r; k < nn + ns; k += 16) {
         float ax, ay, bx, by;
