@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -38,6 +39,7 @@ struct ca_env {
     ObstDev* d_obst = nullptr;
     std::vector<ObstDev> h_obst;
     int P = 1, logP = 0, BS = 64, grid = 1, K = 0, S = 1;
+    int ST = 0, KT = 16;  // solve-kernel variant: ST > 0 = register lines with ST obstacle slots; KT = KMAX
     size_t lds = 0;
     uint64_t steps_done = 0;  // env steps executed (agent_steps = steps_done * A * N)
     float rays[32], oct[32];
@@ -168,7 +170,7 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.goal_x0 = c.goal_x0; a.goal_x1 = c.goal_x1; a.goal_y0 = c.goal_y0; a.goal_y1 = c.goal_y1;
 }
 
-template <int KMAX>
+template <int KMAX, int ST>
 static hipError_t launch_step_k(ca_env* e, const StepArgs& a) {
     const dim3 grid(e->grid), block(e->BS);
     switch (e->BS) {  // neighbour search, then lines + LP + integration + reward/done on the same stream
@@ -177,7 +179,7 @@ static hipError_t launch_step_k(ca_env* e, const StepArgs& a) {
         { ProfScope ps(e, KIND_NBR);                                                                 \
           hipLaunchKernelGGL((nbr_kernel<KMAX, BSZ>), grid, block, 0, e->stream, a); }               \
         { ProfScope ps(e, KIND_STEP);                                                                \
-          hipLaunchKernelGGL((step_kernel<KMAX, BSZ>), grid, block, e->lds, e->stream, a); }         \
+          hipLaunchKernelGGL((step_kernel<KMAX, BSZ, ST>), grid, block, e->lds, e->stream, a); }     \
     }
         case 64: CA_LAUNCH_PAIR(64) break;
         case 128: CA_LAUNCH_PAIR(128) break;
@@ -189,24 +191,25 @@ static hipError_t launch_step_k(ca_env* e, const StepArgs& a) {
     return hipGetLastError();
 }
 static hipError_t launch_step(ca_env* e, const StepArgs& a) {
-    if (e->K <= 5) return launch_step_k<5>(e, a);
-    if (e->K <= 10) return launch_step_k<10>(e, a);
-    return launch_step_k<16>(e, a);
+    if (e->ST > 0) return e->KT == 5 ? launch_step_k<5, 4>(e, a) : launch_step_k<10, 4>(e, a);
+    if (e->K <= 5) return launch_step_k<5, 0>(e, a);
+    if (e->K <= 10) return launch_step_k<10, 0>(e, a);
+    return launch_step_k<16, 0>(e, a);
 }
 
-template <int KMAX, int BS>
+template <int KMAX, int BS, int ST>
 static hipError_t set_lds_attr(size_t lds) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KMAX, BS>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KMAX, BS, ST>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
-template <int KMAX>
+template <int KMAX, int ST>
 static hipError_t set_lds_attr_k(int BS, size_t lds) {
     switch (BS) {
-        case 64: return set_lds_attr<KMAX, 64>(lds);
-        case 128: return set_lds_attr<KMAX, 128>(lds);
-        case 256: return set_lds_attr<KMAX, 256>(lds);
-        case 512: return set_lds_attr<KMAX, 512>(lds);
-        default: return set_lds_attr<KMAX, 1024>(lds);
+        case 64: return set_lds_attr<KMAX, 64, ST>(lds);
+        case 128: return set_lds_attr<KMAX, 128, ST>(lds);
+        case 256: return set_lds_attr<KMAX, 256, ST>(lds);
+        case 512: return set_lds_attr<KMAX, 512, ST>(lds);
+        default: return set_lds_attr<KMAX, 1024, ST>(lds);
     }
 }
 
@@ -284,7 +287,13 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     e->grid = (cfg->n_arenas + apb - 1) / apb;
     e->K = cfg->max_neighbors;
     e->S = cfg->max_obst_neighbors;
-    e->lds = step_lds_bytes(e->BS, e->K, e->S);
+    {   // solve-kernel variant: register-resident ORCA lines when the configuration fits its slots
+        const char* v = getenv("CA_REG_LINES");  // diagnostic switch: 0 forces the LDS line table
+        const bool allow = !(v && v[0] == '0');
+        e->KT = e->K <= 5 ? 5 : (e->K <= 10 ? 10 : 16);
+        e->ST = (allow && e->K <= 10 && e->S <= 4) ? 4 : 0;
+    }
+    e->lds = step_lds_bytes(e->BS, e->K, e->S, e->ST, e->KT);
     host_tables(e);
     const size_t an = AN(e), A = cfg->n_arenas;
     float** f32s[] = {&e->pos_x, &e->pos_y, &e->vel_x, &e->vel_y, &e->pref_x, &e->pref_y, &e->goal_x,
@@ -306,9 +315,10 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     if (r == hipSuccess) r = dalloc(&e->dbg_obs, (size_t)cfg->n_arenas * ((cfg->n_agents + 15) / 16) * 4 * 16);
 #endif
     if (r == hipSuccess && e->lds > 48 * 1024) {
-        if (e->K <= 5) r = set_lds_attr_k<5>(e->BS, e->lds);
-        else if (e->K <= 10) r = set_lds_attr_k<10>(e->BS, e->lds);
-        else r = set_lds_attr_k<16>(e->BS, e->lds);
+        if (e->ST > 0) r = e->KT == 5 ? set_lds_attr_k<5, 4>(e->BS, e->lds) : set_lds_attr_k<10, 4>(e->BS, e->lds);
+        else if (e->K <= 5) r = set_lds_attr_k<5, 0>(e->BS, e->lds);
+        else if (e->K <= 10) r = set_lds_attr_k<10, 0>(e->BS, e->lds);
+        else r = set_lds_attr_k<16, 0>(e->BS, e->lds);
     }
     if (r != hipSuccess) {
         fail(nullptr, CA_EHIP, "ca_create: %s", hipGetErrorString(r));

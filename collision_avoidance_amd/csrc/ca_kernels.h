@@ -12,6 +12,7 @@
 // trajectories agree bit for bit.
 #pragma once
 #include "ca_math.h"
+#include <utility>
 
 namespace ca {
 
@@ -175,6 +176,112 @@ __device__ __noinline__ void lp3(LdsLines ls, int n, int numObst, int begin, flo
     }
 }
 
+// ---- ORCA lines in REGISTERS (the fast path of the solve kernel) ---------------------------------
+// Slots [0, ST) hold this lane's obstacle lines (the first `no` are valid), slots [ST, ST+KMAX) the
+// line of neighbour k (valid for k < ncnt).  Slot order is the contract's line order, so LP2/LP1 run
+// over the slots with every loop fully unrolled: all indices are compile-time constants, the table
+// lives in VGPRs and the clipping loop has no memory latency at all.
+__device__ __forceinline__ float4 pack_line(const Line& l) { return make_float4(l.point.x, l.point.y, l.dir.x, l.dir.y); }
+__device__ __forceinline__ Line unpack_line(const float4& v) { Line l; l.point = mk(v.x, v.y); l.dir = mk(v.z, v.w); return l; }
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>); every index is
+// a constant expression from the start, so the slot array is promoted to registers
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int ML, int ST, int I>
+__device__ __forceinline__ bool lp1_reg(const float4 (&L)[ML], int no, float radius, V2 opt, V2& result) {
+    const Line Li = unpack_line(L[I]);
+    const float dp = dot(Li.point, Li.dir);
+    const float disc = sqr(dp) + sqr(radius) - absSq(Li.point);
+    if (disc < 0.0f) return false;
+    const float sq = sqrtf(disc);
+    float tLeft = -dp - sq;
+    float tRight = -dp + sq;
+    bool failed = false;
+    static_for<I>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        if (j >= ST || j < no) {  // an earlier line that exists
+            const Line M = unpack_line(L[j]);
+            const float den = det(Li.dir, M.dir);
+            const float num = det(M.dir, Li.point - M.point);
+            const bool par = fabsf(den) <= EPS;
+            const float t = num / den;
+            const bool right = !par && den >= 0.0f, left = !par && !(den >= 0.0f);
+            tRight = (right && t < tRight) ? t : tRight;
+            tLeft = (left && tLeft < t) ? t : tLeft;
+            failed = failed || (par ? (num < 0.0f) : (tLeft > tRight));
+        }
+    });
+    if (failed) return false;
+    const float t = dot(Li.dir, opt - Li.point);
+    if (t < tLeft) result = Li.point + tLeft * Li.dir;
+    else if (t > tRight) result = Li.point + tRight * Li.dir;
+    else result = Li.point + t * Li.dir;
+    return true;
+}
+
+// App. A.5 LP2 (dirOpt = false) over the register slots; returns the contract's line index of the
+// first infeasible line, or the line count when all lines are satisfied.
+template <int ML, int ST>
+__device__ __forceinline__ int lp2_reg(const float4 (&L)[ML], int no, int ncnt, float radius, V2 opt, V2& result) {
+    if (absSq(opt) > sqr(radius)) result = normalize(opt) * radius;
+    else result = opt;
+    int fail = no + ncnt;
+    bool alive = true;
+    static_for<ML>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        const bool valid = (i < ST) ? (i < no) : (i - ST < ncnt);
+        if (alive && valid) {
+            const Line Li = unpack_line(L[i]);
+            if (det(Li.dir, Li.point - result) > 0.0f) {
+                const V2 tmp = result;
+                if (!lp1_reg<ML, ST, i>(L, no, radius, opt, result)) {
+                    result = tmp;
+                    fail = (i < ST) ? i : no + (i - ST);
+                    alive = false;
+                }
+            }
+        }
+    });
+    return fail;
+}
+
+// App. A.5 LP3 with both line tables in an LDS pool slot (see the solve kernel)
+__device__ __noinline__ void lp3_pool(LdsLines ls, LdsLines pj, int n, int numObst, int begin, float radius, V2& result) {
+    float distance = 0.0f;
+    for (int i = begin; i < n; ++i) {
+        const Line Li = ls.get(i);
+        if (det(Li.dir, Li.point - result) > distance) {
+            int m = 0;
+            for (int j = 0; j < numObst; ++j) { const Line l0 = ls.get(j); pj.put(m++, l0); }
+            for (int j = numObst; j < i; ++j) {
+                const Line Lj = ls.get(j);
+                Line l;
+                const float d = det(Li.dir, Lj.dir);
+                if (fabsf(d) <= EPS) {
+                    if (dot(Li.dir, Lj.dir) > 0.0f) continue;
+                    l.point = 0.5f * (Li.point + Lj.point);
+                } else {
+                    l.point = Li.point + (det(Lj.dir, Li.point - Lj.point) / d) * Li.dir;
+                }
+                l.dir = normalize(Lj.dir - Li.dir);
+                pj.put(m++, l);
+            }
+            const V2 tmp = result;
+            if (lp2(pj, m, radius, mk(-Li.dir.y, Li.dir.x), true, result) < m) result = tmp;
+            distance = det(Li.dir, Li.point - result);
+        }
+    }
+}
+constexpr int POOL_SLOTS = 16;  // LP3 pool slots per wave (lanes beyond that take another round)
+
 // App. A.4: the half-plane induced by one neighbouring agent (both agents have radius R)
 __device__ __forceinline__ Line agent_orca_line(V2 pos, V2 vel, V2 opos, V2 ovel, float R, float invT, float invDt) {
     const V2 rp = opos - pos;
@@ -227,8 +334,10 @@ __device__ __forceinline__ ObstDev load_obst(const ObstDev* __restrict__ t, int 
 // App. A.3: the half-plane induced by the obstacle edge e.  Returns false when the edge yields no
 // line (already covered, non-convex vertex, foreign leg).  "o1"/"o2" are the edge's two vertices;
 // the oblique cases collapse the edge onto one of them, exactly as the contract's o2<-o1 / o1<-o2.
+// `covered(a, b)`: true when some earlier obstacle line already excludes both scaled end points.
+template <class CoveredFn>
 __device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, int e, V2 pos, V2 vel, float R,
-                                               float invTO, const LdsLines& ls, int nl, Line& line) {
+                                               float invTO, CoveredFn covered, Line& line) {
     const ObstDev E = load_obst(tab, e);
     V2 o1p = mk(E.px, E.py), o2p = mk(E.qx, E.qy);
     V2 o1u = mk(E.ux, E.uy), o2u = mk(E.qux, E.quy);
@@ -237,12 +346,7 @@ __device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, 
     bool same = false;
     const V2 rp1 = o1p - pos;
     const V2 rp2 = o2p - pos;
-    for (int j = 0; j < nl; ++j) {
-        const Line M = ls.get(j);
-        if (det(invTO * rp1 - M.point, M.dir) - invTO * R >= -EPS &&
-            det(invTO * rp2 - M.point, M.dir) - invTO * R >= -EPS)
-            return false;
-    }
+    if (covered(invTO * rp1, invTO * rp2)) return false;
     const float distSq1 = absSq(rp1), distSq2 = absSq(rp2), radiusSq = sqr(R);
     const V2 ov = o2p - o1p;
     const float s = dot(-rp1, ov) / absSq(ov);
@@ -457,7 +561,10 @@ __global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
 }
 
 // LDS carve-up of the step kernel (bytes): lines | px py vx vy | misc ints
-__host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S) {
+// ST = 0: the LDS line table; ST > 0 (register lines): per wave an LP3 pool of POOL_SLOTS slots x
+// (ML lines + ML - 1 projected lines), ML = ST + KMAX
+__host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S, int ST = 0, int KMAX = 0) {
+    if (ST > 0) return (size_t)(BS / 64) * (2 * (ST + KMAX) - 1) * POOL_SLOTS * 16 + (size_t)BS * 32;
     return (size_t)BS * ((size_t)(K + S) * 16 + 16 + 16);
 }
 
@@ -480,9 +587,15 @@ __host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S) {
 #define CA_STAMP(k) do { } while (0)
 #endif
 
-template <int KMAX, int BS>
-__global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
+// ST = 0: ORCA lines in the LDS table [K+S][BS] (any K <= 16, S <= 8).
+// ST > 0: ORCA lines in registers (ST obstacle slots + KMAX neighbour slots), LP2/LP1 fully unrolled,
+//         LP3 through a small per-wave LDS pool.  Needs S <= ST; ~8 KB of LDS per wave instead of
+//         16 KB; built for 4 waves per SIMD (<= 128 VGPRs), i.e. 16 waves per CU: the 4096 arenas
+//         of the C3 workload are all resident at once instead of taking 1.6 rounds at 10 per CU.
+template <int KMAX, int BS, int ST>
+__global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs p) {
     extern __shared__ float4 smem4[];
+    constexpr int ML = ST + KMAX;  // register slots (ST > 0)
     const int tid = threadIdx.x;
     const int P = p.P;
     const int la = tid >> p.logP;
@@ -494,13 +607,14 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     const int q = active ? a * N + i : 0;
     const int lbase = la << p.logP;
 
-    float4* s_lines = smem4;                                   // [(K+S)][BS]
-    float* s_px = reinterpret_cast<float*>(smem4 + (size_t)(K + S) * BS);
+    float4* s_lines = smem4;  // ST = 0: [(K+S)][BS];  ST > 0: [waves][2 ML - 1][POOL_SLOTS]
+    float* s_px = reinterpret_cast<float*>(
+        smem4 + (ST > 0 ? (size_t)(BS / 64) * (2 * ML - 1) * POOL_SLOTS : (size_t)(K + S) * BS));
     float* s_py = s_px + BS;
     float* s_vx = s_py + BS;
     float* s_vy = s_vx + BS;
     int* s_misc = reinterpret_cast<int*>(s_vy + BS);            // [BS][4]
-    LdsLines ls; ls.base = s_lines + tid; ls.stride = BS;
+    LdsLines ls; ls.base = s_lines + tid; ls.stride = BS;       // (ST = 0 only)
 
     CA_STAMP(0);
     // ---- load own state (coalesced SoA) ----
@@ -533,9 +647,92 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
     const int ncnt = active ? p.nb_count[q] : 0;
     CA_STAMP(2);
     CA_STAMP(3);
-    // ---- ORCA lines -> LDS table ----
-    int nl = 0;
     const float R = p.radius;
+    V2 nv = mk(0.0f, 0.0f);
+    if constexpr (ST > 0) {
+        // ================= register path =================
+        float4 L[ML];
+        static_for<ML>([&](auto kc) __attribute__((always_inline)) { L[decltype(kc)::value] = make_float4(0.0f, 0.0f, 1.0f, 0.0f); });
+        int no = 0;  // obstacle lines produced so far (slots [0, no))
+        {
+            const float invTO = 1.0f / p.time_horizon_obst;
+            int e_next = (ocnt > 0) ? p.obst_idx[((size_t)a * S + 0) * N + i] : 0;
+            for (int s = 0; s < S; ++s) {
+                if (s < ocnt) {
+                    const int e = e_next;
+                    if (s + 1 < ocnt) e_next = p.obst_idx[((size_t)a * S + (s + 1)) * N + i];
+                    auto covered = [&](V2 c1, V2 c2) __attribute__((always_inline)) {
+                        bool c = false;
+                        static_for<ST>([&](auto jc) __attribute__((always_inline)) {
+                            constexpr int j = decltype(jc)::value;
+                            const Line M = unpack_line(L[j]);
+                            if (j < no && det(c1 - M.point, M.dir) - invTO * R >= -EPS &&
+                                det(c2 - M.point, M.dir) - invTO * R >= -EPS)
+                                c = true;
+                        });
+                        return c;
+                    };
+                    Line line;
+                    if (obst_orca_line(p.obst, e, pos, vel, R, invTO, covered, line)) {
+                        const float4 pl = pack_line(line);
+                        static_for<ST>([&](auto jc) __attribute__((always_inline)) {
+                            constexpr int j = decltype(jc)::value;
+                            if (j == no) L[j] = pl;  // (a ?: on the struct type would select between addresses)
+                        });
+                        ++no;
+                    }
+                }
+            }
+        }
+        CA_STAMP(4);
+        {
+            const float invT = 1.0f / p.time_horizon;
+            const float invDt = 1.0f / p.time_step;
+            int jn[KMAX];  // all neighbour indices in flight at once
+            static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                jn[k] = (k < ncnt) ? p.nb_idx[((size_t)a * K + k) * N + i] : 0;
+            });
+            static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                if (k < ncnt) {
+                    const int j = lbase + jn[k];
+                    L[ST + k] = pack_line(agent_orca_line(pos, vel, mk(s_px[j], s_py[j]), mk(s_vx[j], s_vy[j]), R, invT, invDt));
+                }
+            });
+        }
+        CA_STAMP(5);
+        // ---- 2-D linear program (App. A.5) on the register slots ----
+        const int nl = no + ncnt;
+        int fail = nl;
+        if (active) fail = lp2_reg<ML, ST>(L, no, ncnt, p.max_speed, pref, nv);
+        CA_STAMP(6);
+        // ---- LP3 for the lanes whose LP2 was infeasible: they copy their lines into a slot of the
+        // wave's LDS pool and solve there; more than POOL_SLOTS such lanes take further rounds ----
+        {
+            float4* pool = s_lines + (size_t)(tid >> 6) * (2 * ML - 1) * POOL_SLOTS;
+            bool need = active && fail < nl;
+            const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+            while (true) {
+                const unsigned long long m = __ballot(need);
+                if (!m) break;
+                const int rank = __popcll(m & below);
+                if (need && rank < POOL_SLOTS) {
+                    LdsLines pls; pls.base = pool + rank; pls.stride = POOL_SLOTS;
+                    LdsLines ppj; ppj.base = pool + (size_t)ML * POOL_SLOTS + rank; ppj.stride = POOL_SLOTS;
+                    static_for<ML>([&](auto kc) __attribute__((always_inline)) {
+                        constexpr int k = decltype(kc)::value;
+                        const bool valid = (k < ST) ? (k < no) : (k - ST < ncnt);
+                        if (valid) pls.base[((k < ST) ? k : no + (k - ST)) * POOL_SLOTS] = L[k];
+                    });
+                    lp3_pool(pls, ppj, nl, no, fail, p.max_speed, nv);
+                    need = false;
+                }
+            }
+        }
+    } else {
+        // ================= LDS-table path =================
+        int nl = 0;
     {
         const float invTO = 1.0f / p.time_horizon_obst;
         int e_next = (ocnt > 0) ? p.obst_idx[((size_t)a * S + 0) * N + i] : 0;
@@ -544,7 +741,15 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
                 const int e = e_next;
                 if (s + 1 < ocnt) e_next = p.obst_idx[((size_t)a * S + (s + 1)) * N + i];
                 Line line;
-                if (obst_orca_line(p.obst, e, pos, vel, R, invTO, ls, nl, line)) {
+                auto covered = [&](V2 c1, V2 c2) {
+                    for (int j = 0; j < nl; ++j) {
+                        const Line M = ls.get(j);
+                        if (det(c1 - M.point, M.dir) - invTO * R >= -EPS && det(c2 - M.point, M.dir) - invTO * R >= -EPS)
+                            return true;
+                    }
+                    return false;
+                };
+                if (obst_orca_line(p.obst, e, pos, vel, R, invTO, covered, line)) {
                     ls.put(nl, line);
                     ++nl;
                 }
@@ -570,13 +775,12 @@ __global__ __launch_bounds__(BS) void step_kernel(const StepArgs p) {
 
     CA_STAMP(5);
     // ---- 2-D linear program (App. A.5) ----
-    V2 nv = mk(0.0f, 0.0f);
     int fail = nl;
     if (active) fail = lp2(ls, nl, p.max_speed, pref, false, nv);
     CA_STAMP(6);
-    if (active) {
-        if (fail < nl) lp3<KMAX + SMAX>(ls, nl, numObstLines, fail, p.max_speed, nv);
-        // ---- integrate (App. A.1) ----
+    if (active && fail < nl) lp3<KMAX + SMAX>(ls, nl, numObstLines, fail, p.max_speed, nv);
+    }
+    if (active) {  // ---- integrate (App. A.1) ----
         vel = nv;
         pos = pos + vel * p.time_step;
     }
