@@ -229,14 +229,20 @@ static hipError_t launch_obs(ca_env* e) {
     o.obst_count = e->obst_count; o.obst_idx = e->obst_idx; o.obst = e->d_obst; o.obs = e->obs;
     o.A = e->cfg.n_arenas; o.N = e->cfg.n_agents; o.S = e->S;
     o.K = e->K > 0 ? e->K : 1;  // nb_idx is allocated with one column when K == 0; counts are all zero
-    o.bpa = (o.N + OBS_APB - 1) / OBS_APB;
+    const int obs_bs = obs_block_threads(o.N), apb = obs_bs / 16;
+    o.bpa = (o.N + apb - 1) / apb;
     o.a0 = 0; o.dbg = e->dbg_obs;
     o.radius = e->cfg.radius;
     memcpy(o.rays, e->rays, sizeof o.rays);
     memcpy(o.oct, e->oct, sizeof o.oct);
-    const dim3 grid((unsigned)((size_t)o.A * o.bpa)), block(OBS_BS);
+    const dim3 grid((unsigned)((size_t)o.A * o.bpa)), block(obs_bs);
+    const size_t lds = obs_lds_bytes(o.N, obs_bs);
     ProfScope ps(e, KIND_OBS);
-    hipLaunchKernelGGL(obs_kernel, grid, block, obs_lds_bytes(o.N), e->stream, o);
+    if (obs_bs == 1024) hipLaunchKernelGGL(obs_kernel<1024>, grid, block, lds, e->stream, o);
+    else if (obs_bs == 512) hipLaunchKernelGGL(obs_kernel<512>, grid, block, lds, e->stream, o);
+    else if (obs_bs == 128) hipLaunchKernelGGL(obs_kernel<128>, grid, block, lds, e->stream, o);
+    else if (obs_bs == 64) hipLaunchKernelGGL(obs_kernel<64>, grid, block, lds, e->stream, o);
+    else hipLaunchKernelGGL(obs_kernel<256>, grid, block, lds, e->stream, o);
     return hipGetLastError();
 }
 
@@ -312,13 +318,23 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     if (r == hipSuccess) r = dalloc(&e->d_obst, (size_t)1);
 #ifdef CA_STAMPS
     if (r == hipSuccess) r = dalloc(&e->dbg, (size_t)e->grid * (e->BS / 64) * 16);
-    if (r == hipSuccess) r = dalloc(&e->dbg_obs, (size_t)cfg->n_arenas * ((cfg->n_agents + 15) / 16) * 4 * 16);
+    if (r == hipSuccess) r = dalloc(&e->dbg_obs, (size_t)cfg->n_arenas * ((cfg->n_agents + 15) / 16 + 16) * 4 * 16);
 #endif
     if (r == hipSuccess && e->lds > 48 * 1024) {
         if (e->ST > 0) r = e->KT == 5 ? set_lds_attr_k<5, 4>(e->BS, e->lds) : set_lds_attr_k<10, 4>(e->BS, e->lds);
         else if (e->K <= 5) r = set_lds_attr_k<5, 0>(e->BS, e->lds);
         else if (e->K <= 10) r = set_lds_attr_k<10, 0>(e->BS, e->lds);
         else r = set_lds_attr_k<16, 0>(e->BS, e->lds);
+    }
+    if (r == hipSuccess) {
+        const int obs_bs = obs_block_threads(cfg->n_agents);
+        const size_t ol = obs_lds_bytes(cfg->n_agents, obs_bs);
+        if (ol > 48 * 1024) {
+            const void* f = obs_bs == 1024 ? reinterpret_cast<const void*>(&obs_kernel<1024>)
+                          : obs_bs == 512 ? reinterpret_cast<const void*>(&obs_kernel<512>)
+                                          : reinterpret_cast<const void*>(&obs_kernel<256>);
+            r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ol);
+        }
     }
     if (r != hipSuccess) {
         fail(nullptr, CA_EHIP, "ca_create: %s", hipGetErrorString(r));
@@ -731,7 +747,10 @@ int ca_launch_info(ca_env* e, int32_t* block, int32_t* grid, int32_t* lds_bytes,
     if (block) *block = e->BS;
     if (grid) *grid = e->grid;
     if (lds_bytes) *lds_bytes = (int32_t)e->lds;
-    if (obs_grid) *obs_grid = (int32_t)((size_t)e->cfg.n_arenas * ((e->cfg.n_agents + OBS_APB - 1) / OBS_APB));
+    if (obs_grid) {
+        const int apb = obs_block_threads(e->cfg.n_agents) / 16;
+        *obs_grid = (int32_t)((size_t)e->cfg.n_arenas * ((e->cfg.n_agents + apb - 1) / apb));
+    }
     return CA_OK;
 }
 

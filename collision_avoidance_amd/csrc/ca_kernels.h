@@ -536,8 +536,10 @@ __global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
     int ncnt = 0;
     if (K > 0) {
         float rangeSq = sqr(p.neighbor_dist);
+        V2 o_next = mk(s_px[lbase], s_py[lbase]);
         for (int j = 0; j < N; ++j) {
-            const V2 o = mk(s_px[lbase + j], s_py[lbase + j]);
+            const V2 o = o_next;  // the next candidate's position is in flight while this one is inserted
+            if (j + 1 < N) o_next = mk(s_px[lbase + j + 1], s_py[lbase + j + 1]);
             const float dsq = absSq(pos - o);
             if (active && j != i && dsq < rangeSq) {
                 sorted_insert<KMAX>(nkey, make_key(dsq, j));
@@ -997,7 +999,7 @@ struct ObsArgs {
         const unsigned long long _t = __builtin_amdgcn_s_memtime();                        \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                \
         if ((threadIdx.x & 63) == 0 && p.dbg)                                              \
-            p.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = _t;          \
+            p.dbg[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = _t; \
         __builtin_amdgcn_sched_barrier(0);                                                 \
     } while (0)
 #else
@@ -1012,15 +1014,23 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-constexpr int OBS_BS = 256;
-constexpr int OBS_APB = OBS_BS / 16;  // agents per workgroup
+// The observation workgroup: OBS_BS lanes = OBS_BS/16 agents of ONE arena (template parameter: 256,
+// 512 or 1024 lanes, so that a workgroup can own a whole arena of up to 64 agents and stage it once).
 constexpr int OBS_PAIRCAP = 16 * (16 + 8);  // (source, ray) pairs of one agent: <= 16 rays x (K + S) sources
 
 // LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | nb idx [16][16] | obstacle idx [16][8]
 //              | ray and octagon tables [64] | pair counts [16] | (source, ray) pair lists [16][384] u16
-__host__ __device__ inline size_t obs_lds_bytes(int N) {
-    return (size_t)N * 16 + OBS_APB * 16 * 8 + OBS_APB * 16 * 4 + OBS_APB * 8 * 4 + 64 * 4 + OBS_APB * 4 +
-           (size_t)OBS_APB * OBS_PAIRCAP * 2;
+__host__ __device__ inline size_t obs_lds_bytes(int N, int obs_bs) {
+    const size_t apb = obs_bs / 16;
+    return (size_t)N * 16 + apb * 16 * 8 + apb * 16 * 4 + apb * 8 * 4 + 64 * 4 + apb * 4 + apb * OBS_PAIRCAP * 2;
+}
+#ifndef CA_OBS_BS_MAX
+#define CA_OBS_BS_MAX 256
+#endif
+// 256 lanes measured best (C3: 99 us; 512 lanes: see profiles/r01_k_obs_variants.txt; 1024 lanes: 127 us)
+__host__ __device__ inline int obs_block_threads(int N) {
+    const int want = N > 32 ? 1024 : (N > 16 ? 512 : 256);
+    return want < CA_OBS_BS_MAX ? want : CA_OBS_BS_MAX;
 }
 
 struct SegGeom {  // one segment in the goal-aligned frame, in the reference's intermediate terms
@@ -1054,7 +1064,9 @@ __device__ __forceinline__ float ray_dial(float x, float y) {
 // is < 1e-4 and the margin is 0.01 dial units (3.9e-3 rad).  Segments passing (almost) through the
 // origin, where "short way round" is ill-defined, get all 16 rays.  For an agent NEIGHBOUR the
 // window is that of the circle through its octagon's vertices (see the pre-pass).
+template <int OBS_BS>
 __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
+    constexpr int OBS_APB = OBS_BS / 16;  // agents per workgroup
     extern __shared__ float4 smem4[];
     const int tid = threadIdx.x;
     const int g = tid >> 4, r = tid & 15;
