@@ -300,6 +300,14 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->ST = (allow && e->K <= 10 && e->S <= 4) ? 4 : 0;
     }
     e->lds = step_lds_bytes(e->BS, e->K, e->S, e->ST, e->KT);
+    if (e->lds > 160 * 1024) {
+        fail(nullptr, CA_ERANGE, "ca_create: the solve kernel would need %zu B of LDS (> 160 KiB) for n_agents=%d, "
+             "max_neighbors=%d, max_obst_neighbors=%d: arenas above 256 agents need max_neighbors <= 10 and "
+             "max_obst_neighbors <= 4 (register-line variant)", e->lds, cfg->n_agents, e->K, e->S);
+        if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+        delete e;
+        return CA_ERANGE;
+    }
     host_tables(e);
     const size_t an = AN(e), A = cfg->n_arenas;
     float** f32s[] = {&e->pos_x, &e->pos_y, &e->vel_x, &e->vel_y, &e->pref_x, &e->pref_y, &e->goal_x,
@@ -340,12 +348,6 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         fail(nullptr, CA_EHIP, "ca_create: %s", hipGetErrorString(r));
         ca_destroy(e);
         return CA_EHIP;
-    }
-    if (e->lds > 160 * 1024) {
-        fail(nullptr, CA_ERANGE, "ca_create: step kernel needs %zu B of LDS (> 160 KiB): lower n_agents, "
-             "max_neighbors or max_obst_neighbors", e->lds);
-        ca_destroy(e);
-        return CA_ERANGE;
     }
     *out = e;
     return CA_OK;

@@ -30,7 +30,8 @@ extern "C" {
 #define CA_N_RAYS 16
 #define CA_MAX_NEIGHBORS 16      /* largest supported max_neighbors       */
 #define CA_MAX_OBST_NEIGHBORS 8  /* largest supported max_obst_neighbors  */
-#define CA_MAX_AGENTS 1024       /* one workgroup owns one arena          */
+#define CA_MAX_AGENTS 1024       /* one workgroup owns one arena; above 256 agents max_neighbors <= 10
+                                    and max_obst_neighbors <= 4 are required (LDS capacity)              */
 
 /* error codes */
 #define CA_OK 0

@@ -82,6 +82,9 @@ CASES = [
     ("incoming", 6, 17, "incoming", dict(), 400, 100),
     ("congested", 6, 24, "congested", dict(), 500, 100),
     ("blocks", 6, 12, "blocks", dict(), 500, 100),
+    # the largest workgroup shapes: 1024 lanes (register lines) and the LDS line table with K = 16
+    ("n1000", 1, 1000, "crowd", dict(), 12, 6),
+    ("n250k16", 2, 250, "crowd", dict(max_neighbors=16, neighbor_dist=4.0), 20, 10),
 ]
 
 
@@ -140,6 +143,16 @@ def test_obs_adversarial_geometry():
         H.assert_state_equal(gpu, orc, "adversarial reset %d" % s, obs=True)
     assert np.abs(gpu.get(_lib.FLD_OBS)).max() > 0
     gpu.close()
+
+
+def test_configurations_that_do_not_fit_are_refused():
+    """K > 10 forces the LDS line table: (K + S) x 16 B per lane must fit 160 KiB with the arena in one
+    workgroup.  The library must say so instead of failing inside HIP."""
+    p = H.scenario_params("crowd", 700, max_neighbors=16)
+    with pytest.raises(RuntimeError, match="LDS"):
+        H.make_gpu(1, 700, "crowd", p)
+    with pytest.raises(RuntimeError, match="out of range"):
+        H.make_gpu(1, 1025, "crowd", H.scenario_params("crowd", 1025))
 
 
 def test_regoal_and_rollout_call():
