@@ -24,9 +24,9 @@ struct ca_env {
     bool own_stream = false;
     // [A*N] fp32
     float *pos_x = nullptr, *pos_y = nullptr, *vel_x = nullptr, *vel_y = nullptr, *pref_x = nullptr,
-          *pref_y = nullptr, *goal_x = nullptr, *goal_y = nullptr, *goal2_x = nullptr, *goal2_y = nullptr,
-          *reward = nullptr, *orient_x = nullptr, *orient_y = nullptr;
+          *pref_y = nullptr, *reward = nullptr, *orient_x = nullptr, *orient_y = nullptr;
     bool orient_valid = false;  // orient_x/y match pos/goal (false after the caller edits them)
+    double *goal_x = nullptr, *goal_y = nullptr, *goal2_x = nullptr, *goal2_y = nullptr;  // fp64 targets
     int *agent_done = nullptr, *arrive_step = nullptr, *regoal_count = nullptr, *nb_count = nullptr,
         *nb_idx = nullptr, *obst_count = nullptr, *obst_idx = nullptr;
     int *step_count = nullptr, *arena_done = nullptr, *episode = nullptr;
@@ -107,10 +107,10 @@ static FieldInfo field_info(ca_env* e, int f) {
         case CA_FLD_VEL_Y: return {e->vel_y, an * 4, true};
         case CA_FLD_PREF_X: return {e->pref_x, an * 4, true};
         case CA_FLD_PREF_Y: return {e->pref_y, an * 4, true};
-        case CA_FLD_GOAL_X: return {e->goal_x, an * 4, true};
-        case CA_FLD_GOAL_Y: return {e->goal_y, an * 4, true};
-        case CA_FLD_GOAL2_X: return {e->goal2_x, an * 4, true};
-        case CA_FLD_GOAL2_Y: return {e->goal2_y, an * 4, true};
+        case CA_FLD_GOAL_X: return {e->goal_x, an * 8, true};
+        case CA_FLD_GOAL_Y: return {e->goal_y, an * 8, true};
+        case CA_FLD_GOAL2_X: return {e->goal2_x, an * 8, true};
+        case CA_FLD_GOAL2_Y: return {e->goal2_y, an * 8, true};
         case CA_FLD_REWARD: return {e->reward, an * 4, false};
         case CA_FLD_AGENT_DONE: return {e->agent_done, an * 4, true};
         case CA_FLD_ARRIVE_STEP: return {e->arrive_step, an * 4, true};
@@ -310,10 +310,11 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     }
     host_tables(e);
     const size_t an = AN(e), A = cfg->n_arenas;
-    float** f32s[] = {&e->pos_x, &e->pos_y, &e->vel_x, &e->vel_y, &e->pref_x, &e->pref_y, &e->goal_x,
-                      &e->goal_y, &e->goal2_x, &e->goal2_y, &e->reward, &e->tmp_x, &e->tmp_y,
-                      &e->orient_x, &e->orient_y};
+    float** f32s[] = {&e->pos_x, &e->pos_y, &e->vel_x, &e->vel_y, &e->pref_x, &e->pref_y, &e->reward,
+                      &e->tmp_x, &e->tmp_y, &e->orient_x, &e->orient_y};
     for (auto p : f32s) if (r == hipSuccess) r = dalloc(p, an);
+    double** f64s[] = {&e->goal_x, &e->goal_y, &e->goal2_x, &e->goal2_y};
+    for (auto p : f64s) if (r == hipSuccess) r = dalloc(p, an);
     int** i32s[] = {&e->agent_done, &e->arrive_step, &e->regoal_count, &e->nb_count, &e->obst_count};
     for (auto p : i32s) if (r == hipSuccess) r = dalloc(p, an);
     if (r == hipSuccess) r = dalloc(&e->nb_idx, an * (size_t)(e->K > 0 ? e->K : 1));
@@ -428,7 +429,8 @@ int ca_init_scenario(ca_env* e, int32_t scenario) {
     const ca_config& c = e->cfg;
     const int A = c.n_arenas, N = c.n_agents;
     const size_t an = AN(e);
-    std::vector<float> px(an), py(an), vx(an), vy(an), gx(an), gy(an), g2x(an), g2y(an), fx(an), fy(an);
+    std::vector<float> px(an), py(an), vx(an), vy(an), fx(an), fy(an);
+    std::vector<double> gx(an), gy(an), g2x(an), g2y(an);
     const double r = (double)c.radius;
     for (int a = 0; a < A; ++a) {
         const int64_t g = c.arena_offset + a;
@@ -444,14 +446,14 @@ int ca_init_scenario(ca_env* e, int32_t scenario) {
                 rng2(c.seed, g, i, RNG_POS, 0, &u0, &u1);
                 px[q] = (float)uniform64(0.0, E, u0); py[q] = (float)uniform64(0.0, E, u1);
                 rng2(c.seed, g, i, RNG_GOAL, 0, &u0, &u1);
-                gx[q] = (float)uniform64(0.0, E, u0); gy[q] = (float)uniform64(0.0, E, u1);
+                gx[q] = uniform64(0.0, E, u0); gy[q] = uniform64(0.0, E, u1);
                 g2x[q] = gx[q]; g2y[q] = gy[q];
             } else if (scenario == CA_SCN_CIRCLE) {  // ALAN:297-322
                 const double R = (r * 3 * N) / (2.0 * M_PI);
                 const double E = 2.0 * R + 4.0 * r;
                 px[q] = (float)(E / 2 + R * std::cos(theta)); py[q] = (float)(E / 2 + R * std::sin(theta));
-                gx[q] = (float)(E / 2 + R * std::cos(theta + M_PI));
-                gy[q] = (float)(E / 2 + R * std::sin(theta + M_PI));
+                gx[q] = E / 2 + R * std::cos(theta + M_PI);
+                gy[q] = E / 2 + R * std::sin(theta + M_PI);
                 g2x[q] = gx[q]; g2y[q] = gy[q];
                 theta += (2.0 * M_PI) / N;
             } else if (scenario >= CA_SCN_CONGESTED) {  // ALAN:175-193, 213-258, 333-357, 377-416
@@ -492,13 +494,13 @@ int ca_init_scenario(ca_env* e, int32_t scenario) {
                     }
                     y = E / 2; ty = t2y = E / 2;
                 }
-                px[q] = (float)x; py[q] = (float)y; gx[q] = (float)tx; gy[q] = (float)ty;
-                g2x[q] = (float)t2x; g2y[q] = (float)t2y;
+                px[q] = (float)x; py[q] = (float)y; gx[q] = tx; gy[q] = ty;
+                g2x[q] = t2x; g2y[q] = t2y;
             } else {  // env.py:86-95, 361
                 const double E = 10.0;
                 rng2(c.seed, g, i, RNG_POS, 0, &u0, &u1);
                 px[q] = (float)uniform64(E * 0.5, E, u0); py[q] = (float)uniform64(0.0, E, u1);
-                gx[q] = 1.0f; gy[q] = 5.0f; g2x[q] = -10.0f; g2y[q] = 5.0f;
+                gx[q] = 1.0; gy[q] = 5.0; g2x[q] = -10.0; g2y[q] = 5.0;
             }
             double dx, dy;  // env.py:97 update_pref_vel
             pref_dir64(px[q], py[q], gx[q], gy[q], &dx, &dy);
@@ -507,10 +509,12 @@ int ca_init_scenario(ca_env* e, int32_t scenario) {
     }
     HIPCHK(e, hipSetDevice(e->device));
     struct { float* d; std::vector<float>* h; } up[] = {{e->pos_x, &px}, {e->pos_y, &py}, {e->vel_x, &vx},
-        {e->vel_y, &vy}, {e->goal_x, &gx}, {e->goal_y, &gy}, {e->goal2_x, &g2x}, {e->goal2_y, &g2y},
-        {e->pref_x, &fx}, {e->pref_y, &fy}};
+        {e->vel_y, &vy}, {e->pref_x, &fx}, {e->pref_y, &fy}};
+    struct { double* d; std::vector<double>* h; } upd[] = {{e->goal_x, &gx}, {e->goal_y, &gy},
+        {e->goal2_x, &g2x}, {e->goal2_y, &g2y}};
     HIPCHK(e, hipStreamSynchronize(e->stream));
     for (auto& u : up) HIPCHK(e, hipMemcpy(u.d, u.h->data(), an * 4, hipMemcpyHostToDevice));
+    for (auto& u : upd) HIPCHK(e, hipMemcpy(u.d, u.h->data(), an * 8, hipMemcpyHostToDevice));
     HIPCHK(e, hipMemset(e->agent_done, 0, an * 4));
     HIPCHK(e, hipMemset(e->arrive_step, 0xff, an * 4));
     HIPCHK(e, hipMemset(e->regoal_count, 0, an * 4));

@@ -34,8 +34,9 @@ struct Line {
 };
 
 struct StepArgs {
-    float *pos_x, *pos_y, *vel_x, *vel_y, *pref_x, *pref_y, *goal_x, *goal_y;
-    const float *goal2_x, *goal2_y;
+    float *pos_x, *pos_y, *vel_x, *vel_y, *pref_x, *pref_y;
+    double *goal_x, *goal_y;        // targets stay fp64 like the reference's Python floats
+    const double *goal2_x, *goal2_y;
     float* reward;
     float *orient_x, *orient_y;  // unit vector pos -> goal of the CURRENT state (frame of the observation)
     int *agent_done, *arrive_step, *regoal_count;
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     CA_STAMP(0);
     // ---- load own state (coalesced SoA) ----
     V2 pos = mk(0.0f, 0.0f), vel = mk(0.0f, 0.0f), pref = mk(0.0f, 0.0f);
-    float gx = 0.0f, gy = 0.0f;
+    double gx = 0.0, gy = 0.0;
     int done = 1;
     double pf_x = 1.0, pf_y = 0.0, rl_x = 1.0, rl_y = 0.0;
     if (active) {
@@ -838,7 +839,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
         if (p.done_mode == 0) {
             hit = (done == 0) && (pos.x < p.done_x_thresh);
         } else {
-            const double dx = (double)pos.x - (double)gx, dy = (double)pos.y - (double)gy;
+            const double dx = (double)pos.x - gx, dy = (double)pos.y - gy;
             const double lim = 2.0 * (double)p.radius;
             hit = (dx * dx + dy * dy) < lim * lim;
             if (p.done_mode == 1) hit = hit && (done == 0);
@@ -848,8 +849,8 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
                 const int rc = p.regoal_count[q];
                 double u0, u1;
                 rng2(p.seed, p.arena_offset + a, i, RNG_REGOAL, (uint32_t)rc, &u0, &u1);
-                gx = (float)uniform64((double)p.goal_x0, (double)p.goal_x1, u0);
-                gy = (float)uniform64((double)p.goal_y0, (double)p.goal_y1, u1);
+                gx = uniform64((double)p.goal_x0, (double)p.goal_x1, u0);
+                gy = uniform64((double)p.goal_y0, (double)p.goal_y1, u1);
                 p.regoal_count[q] = rc + 1;
             } else {
                 done = 1;
@@ -1292,7 +1293,7 @@ __global__ void debug_math_kernel(int op, const void* in, void* out, int n, uint
     } else if (op == 3) {
         const float* f = (const float*)in + 4 * t;
         double x, y;
-        pref_dir64(f[0], f[1], f[2], f[3], &x, &y);
+        pref_dir64(f[0], f[1], (double)f[2], (double)f[3], &x, &y);
         ((double*)out)[2 * t] = x; ((double*)out)[2 * t + 1] = y;
     } else if (op == 4) {
         const uint32_t* u = (const uint32_t*)in + 4 * t;

@@ -58,10 +58,11 @@ CA_HD void sincos64(double a, double* s, double* c) {
     *c = (q == 0) ? cp : (q == 1) ? -sp : (q == 2) ? -cp : sp;
 }
 
-// env.py:156-162 comp_pref_vel: unit vector from pos to goal in fp64; zero vector -> (1, 0)
-CA_HD void pref_dir64(float px, float py, float gx, float gy, double* ox, double* oy) {
-    const double dx = (double)gx - (double)px;
-    const double dy = (double)gy - (double)py;
+// env.py:156-162 comp_pref_vel: unit vector from pos to goal in fp64; zero vector -> (1, 0).
+// Positions are the simulator's fp32, targets are fp64 (Python floats in the reference).
+CA_HD void pref_dir64(float px, float py, double gx, double gy, double* ox, double* oy) {
+    const double dx = gx - (double)px;
+    const double dy = gy - (double)py;
     const bool z = (dx == 0.0 && dy == 0.0);
     const double len = z ? 1.0 : sqrt(dx * dx + dy * dy);
     *ox = z ? 1.0 : dx / len;

@@ -21,6 +21,7 @@ _I32_FIELDS = {_lib.FLD_AGENT_DONE, _lib.FLD_ARRIVE_STEP, _lib.FLD_NB_COUNT, _li
                _lib.FLD_OBST_COUNT, _lib.FLD_OBST_IDX, _lib.FLD_STEP_COUNT, _lib.FLD_ARENA_DONE,
                _lib.FLD_EPISODE, _lib.FLD_REGOAL_COUNT}
 _ARENA_FIELDS = {_lib.FLD_STEP_COUNT, _lib.FLD_ARENA_DONE, _lib.FLD_EPISODE}
+_F64_FIELDS = {_lib.FLD_GOAL_X, _lib.FLD_GOAL_Y, _lib.FLD_GOAL2_X, _lib.FLD_GOAL2_Y}
 
 
 def _ptr(a):
@@ -93,7 +94,7 @@ class VecCollisionAvoidanceEnv:
             pass
 
     def _shape_dtype(self, field):
-        dt = np.int32 if field in _I32_FIELDS else np.float32
+        dt = np.int32 if field in _I32_FIELDS else (np.float64 if field in _F64_FIELDS else np.float32)
         if field in _ARENA_FIELDS:
             return (self.A,), dt
         if field == _lib.FLD_NB_IDX:

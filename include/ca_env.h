@@ -13,7 +13,8 @@
  *     last failed ca_create on this thread).
  *   - a handle is bound to one HIP device and one stream; calls are asynchronous on that stream
  *     unless stated otherwise.  A handle is not thread-safe; distinct handles are independent.
- *   - all per-agent arrays are struct-of-arrays fp32/int32 of shape [A, N] (agent index fastest).
+ *   - all per-agent arrays are struct-of-arrays fp32/int32 (targets: fp64) of shape [A, N] (agent index
+ *     fastest).
  *   - there is NO CPU fallback: without a HIP device ca_create fails with CA_ENODEV.
  */
 #ifndef CA_ENV_H
@@ -64,7 +65,9 @@ extern "C" {
 /* fields for ca_get / ca_set / ca_field_ptr */
 enum ca_field {
     CA_FLD_POS_X = 0, CA_FLD_POS_Y, CA_FLD_VEL_X, CA_FLD_VEL_Y, CA_FLD_PREF_X, CA_FLD_PREF_Y,
-    CA_FLD_GOAL_X, CA_FLD_GOAL_Y, CA_FLD_GOAL2_X, CA_FLD_GOAL2_Y,
+    CA_FLD_GOAL_X, CA_FLD_GOAL_Y, CA_FLD_GOAL2_X, CA_FLD_GOAL2_Y, /* f64 [A,N]: the reference keeps its
+                                   targets as Python floats (env.py:94, ALAN:186) and derives the
+                                   preferred velocity from them in fp64 */
     CA_FLD_REWARD,       /* f32 [A,N]                                             */
     CA_FLD_AGENT_DONE,   /* i32 [A,N]                                             */
     CA_FLD_ARRIVE_STEP,  /* i32 [A,N]                                             */

@@ -461,11 +461,56 @@ void sincos64(double a, double* s, double* c) {
     }
 }
 
+/* e^x by k = round(x/ln2), r = x - k ln2 (two-part), a degree-13 Taylor polynomial in Horner form
+ * and an exact scaling by 2^k: single IEEE operations only, |x| <~ 700, error <~ 2e-16 relative */
+double exp64(double x) {
+    const double kd = std::floor(x * 1.44269504088896338700e+00 + 0.5);
+    const double r = (x - kd * 6.93147180369123816490e-01) - kd * 1.90821492927058770002e-10;
+    double pl = 1.0 / 6227020800.0;
+    pl = pl * r + 1.0 / 479001600.0;
+    pl = pl * r + 1.0 / 39916800.0;
+    pl = pl * r + 1.0 / 3628800.0;
+    pl = pl * r + 1.0 / 362880.0;
+    pl = pl * r + 1.0 / 40320.0;
+    pl = pl * r + 1.0 / 5040.0;
+    pl = pl * r + 1.0 / 720.0;
+    pl = pl * r + 1.0 / 120.0;
+    pl = pl * r + 1.0 / 24.0;
+    pl = pl * r + 1.0 / 6.0;
+    pl = pl * r + 0.5;
+    pl = pl * r + 1.0;
+    pl = pl * r + 1.0;
+    const long long k = (long long)kd;
+    uint64_t bits = (uint64_t)(k + 1023) << 52;
+    double scale;
+    std::memcpy(&scale, &bits, 8);
+    return pl * scale;
+}
+
+/* numpy's float64 sum for short arrays (pairwise_sum: < 8 sequential; otherwise 8 accumulators
+ * combined as a tree, then the tail) -- what `np.sum(ps)` at ALAN_true.py:582 computes */
+double np_sum(const double* a, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
 /* env.py:156-162 comp_pref_vel: (cos, sin) of atan2(goal - pos) in fp64 == the normalised
- * difference; atan2(0,0) = 0 -> (1,0).  Inputs are fp32-valued, differences exact in fp64. */
-void pref_dir64(float px, float py, float gx, float gy, double* ox, double* oy) {
-    const double dx = (double)gx - (double)px;
-    const double dy = (double)gy - (double)py;
+ * difference; atan2(0,0) = 0 -> (1,0).  Positions are fp32 (the simulator's), targets fp64 (the
+ * reference keeps them as Python floats, env.py:94, ALAN_true.py:186-187). */
+void pref_dir64(float px, float py, double gx, double gy, double* ox, double* oy) {
+    const double dx = gx - (double)px;
+    const double dy = gy - (double)py;
     if (dx == 0.0 && dy == 0.0) {
         *ox = 1.0;
         *oy = 0.0;
@@ -494,7 +539,7 @@ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
 }
 
 /* purposes of a draw */
-enum { RNG_POS = 0, RNG_HEADING = 1, RNG_GOAL = 2, RNG_REGOAL = 3, RNG_RESET = 4 };
+enum { RNG_POS = 0, RNG_HEADING = 1, RNG_GOAL = 2, RNG_REGOAL = 3, RNG_RESET = 4, RNG_ALAN = 5 };
 
 /* two uniform doubles in [0,1) with 53 random bits each, keyed by (seed, arena, agent, purpose, seq) */
 void rng2(uint64_t seed, int64_t arena, int agent, int purpose, uint32_t seq, double* u0, double* u1) {
@@ -603,13 +648,20 @@ struct Env {
     orc_config cfg;
     std::vector<ObstVertex> obst;
     std::vector<Arena> arenas;
-    std::vector<float> goal_x, goal_y, goal2_x, goal2_y, reward, obs;
+    std::vector<double> goal_x, goal_y, goal2_x, goal2_y;  /* fp64 like the reference's target tuples */
+    std::vector<float> reward, obs;
     std::vector<double> reward64, obs64;
     std::vector<int32_t> agent_done, arrive_step, regoal_count;
     std::vector<int32_t> step_count, arena_done, episode;
     std::vector<double> rl64;   /* scratch: action-rotated preferred direction, [A*N*2] */
     std::vector<double> pf64;   /* scratch: goal direction before the step, [A*N*2]     */
     std::vector<orc_stats> st;  /* per arena, summed on read                             */
+    /* ALAN online learning state (ALAN_true.py:30-49, 141-142) */
+    int n_actions = 0;
+    double alan_temp = 0.2, alan_window = 2.0, alan_dt = 1.0 / 60.0;  /* Python floats of the reference */
+    std::vector<double> act_c, act_s;          /* unit action vectors                    */
+    std::vector<double> alan_w, alan_t;        /* [A*N*nA]                               */
+    std::vector<int32_t> alan_action;          /* [A*N]                                  */
     double rays64[32], oct64[32];
     float rays32[32], oct32[32];
     int A() const { return cfg.n_arenas; }
@@ -722,8 +774,8 @@ int arena_done_test(Env& e, int a) {
                 e.st[a].goals_reached += 1;
             }
         } else {
-            const double dx = (double)ar.pos[i].x - (double)e.goal_x[q];
-            const double dy = (double)ar.pos[i].y - (double)e.goal_y[q];
+            const double dx = (double)ar.pos[i].x - e.goal_x[q];
+            const double dy = (double)ar.pos[i].y - e.goal_y[q];
             const double lim = 2.0 * (double)c.radius;
             const bool reached = (dx * dx + dy * dy) < lim * lim; /* ALAN:555 */
             if (c.done_mode == ORC_DONE_GOAL) {
@@ -737,8 +789,8 @@ int arena_done_test(Env& e, int a) {
             } else if (reached) {
                 double u0, u1;
                 rng2(c.seed, c.arena_offset + a, i, RNG_REGOAL, (uint32_t)e.regoal_count[q], &u0, &u1);
-                e.goal_x[q] = (float)uniform64((double)c.goal_x0, (double)c.goal_x1, u0);
-                e.goal_y[q] = (float)uniform64((double)c.goal_y0, (double)c.goal_y1, u1);
+                e.goal_x[q] = uniform64((double)c.goal_x0, (double)c.goal_x1, u0);
+                e.goal_y[q] = uniform64((double)c.goal_y0, (double)c.goal_y1, u1);
                 e.regoal_count[q] += 1;
                 e.st[a].goals_reached += 1;
             }
@@ -831,6 +883,63 @@ void arena_step(Env& e, int a, const float* actions, uint32_t flags, int prec) {
         e.st[a].episodes += 1;
         if (flags & ORC_F_AUTORESET) arena_reset(e, a, nullptr, nullptr);
     }
+    if (flags & ORC_F_OBS) arena_obs(e, a, prec);
+}
+
+/* ALAN_true.py:569-628 online_step for one arena (+ the step counter / done test of run_sim,
+ * ALAN_true.py:119-121).  u: this arena's uniforms [N] or null. */
+void arena_alan_step(Env& e, int a, const double* u, uint32_t flags, int prec) {
+    Arena& ar = e.arenas[a];
+    const int N = e.N(), nA = e.n_actions;
+    const orc_config& c = e.cfg;
+    std::vector<double> ps(nA), cdf(nA);
+    for (int i = 0; i < N; ++i) {
+        const size_t q = (size_t)a * N + i;
+        double* w = &e.alan_w[q * nA];
+        for (int k = 0; k < nA; ++k) ps[k] = exp64(w[k] / e.alan_temp);   /* :580-581 */
+        const double sum = np_sum(ps.data(), nA);
+        for (int k = 0; k < nA; ++k) ps[k] /= sum;                          /* :582 */
+        /* np.random.choice(n, 1, p=ps): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, 'right') */
+        double acc = 0.0;
+        for (int k = 0; k < nA; ++k) { acc += ps[k]; cdf[k] = acc; }
+        for (int k = 0; k < nA; ++k) cdf[k] /= acc;
+        double ui;
+        if (u) ui = u[i];
+        else { double u1; rng2(c.seed, c.arena_offset + a, i, RNG_ALAN, (uint32_t)e.step_count[a], &ui, &u1); }
+        int id = 0;
+        while (id < nA - 1 && !(cdf[id] > ui)) ++id;
+        e.alan_action[q] = id;
+        double gx, gy;
+        pref_dir64(ar.pos[i].x, ar.pos[i].y, e.goal_x[q], e.goal_y[q], &gx, &gy);   /* :588 */
+        const double cs = e.act_c[id], sn = e.act_s[id];                             /* :592-595 */
+        const double lx = gx * cs - gy * sn, ly = gx * sn + gy * cs;
+        e.pf64[2 * q] = gx; e.pf64[2 * q + 1] = gy;
+        e.rl64[2 * q] = lx; e.rl64[2 * q + 1] = ly;
+        ar.pref[i] = mk((float)lx, (float)ly);                                        /* :598 */
+    }
+    do_step(ar, e.obst, c.time_step, c.max_obst_neighbors, &e.st[a].obst_overflow);  /* :601 */
+    e.st[a].agent_steps += (uint64_t)N;
+    if (flags & ORC_F_STATS) arena_collisions(e, a);
+    if (prec == ORC_PREC_F64) arena_reward<double>(e, a);
+    else arena_reward<float>(e, a);
+    for (int i = 0; i < N; ++i) { /* :606-628: the weights are Python floats: always from the fp64 reward */
+        const size_t q = (size_t)a * N + i;
+        const double vx = (double)ar.vel[i].x, vy = (double)ar.vel[i].y;
+        const double R = c.reward_scale * (vx * e.pf64[2 * q] + vy * e.pf64[2 * q + 1]) +
+                         (1.0 - c.reward_scale) * (vx * e.rl64[2 * q] + vy * e.rl64[2 * q + 1]);
+        double* w = &e.alan_w[q * nA];
+        double* t = &e.alan_t[q * nA];
+        for (int k = 0; k < nA; ++k) {
+            t[k] += e.alan_dt;
+            if (t[k] >= e.alan_window) { t[k] = 0.0; w[k] = 0.0; }
+        }
+        w[e.alan_action[q]] = R;
+    }
+    e.step_count[a] += 1;                                   /* ALAN:120 */
+    int all_done = arena_done_test(e, a);                   /* ALAN:121 */
+    if (c.max_step > 0 && e.step_count[a] >= c.max_step) all_done = 1;
+    e.arena_done[a] = all_done;
+    if (all_done) e.st[a].episodes += 1;
     if (flags & ORC_F_OBS) arena_obs(e, a, prec);
 }
 
@@ -936,8 +1045,8 @@ int orc_env_init_scenario(void* env, int32_t scenario) {
                 rng2(c.seed, g, i, RNG_POS, 0, &u0, &u1);
                 ar.pos[i] = mk((float)uniform64(0.0, E, u0), (float)uniform64(0.0, E, u1));
                 rng2(c.seed, g, i, RNG_GOAL, 0, &u0, &u1);
-                e->goal_x[q] = (float)uniform64(0.0, E, u0);
-                e->goal_y[q] = (float)uniform64(0.0, E, u1);
+                e->goal_x[q] = uniform64(0.0, E, u0);
+                e->goal_y[q] = uniform64(0.0, E, u1);
                 e->goal2_x[q] = e->goal_x[q];
                 e->goal2_y[q] = e->goal_y[q];
             } else if (scenario == ORC_SCN_CIRCLE) { /* ALAN:297-322 */
@@ -945,8 +1054,8 @@ int orc_env_init_scenario(void* env, int32_t scenario) {
                 const double R = circ / (2.0 * M_PI);
                 const double E = 2.0 * R + 4.0 * r;
                 ar.pos[i] = mk((float)(E / 2 + R * std::cos(theta)), (float)(E / 2 + R * std::sin(theta)));
-                e->goal_x[q] = (float)(E / 2 + R * std::cos(theta + M_PI));
-                e->goal_y[q] = (float)(E / 2 + R * std::sin(theta + M_PI));
+                e->goal_x[q] = E / 2 + R * std::cos(theta + M_PI);
+                e->goal_y[q] = E / 2 + R * std::sin(theta + M_PI);
                 e->goal2_x[q] = e->goal_x[q];
                 e->goal2_y[q] = e->goal_y[q];
                 theta += (2.0 * M_PI) / N;
@@ -954,8 +1063,8 @@ int orc_env_init_scenario(void* env, int32_t scenario) {
                 const double E = 10.0;
                 rng2(c.seed, g, i, RNG_POS, 0, &u0, &u1);
                 ar.pos[i] = mk((float)uniform64(E * 0.5, E, u0), (float)uniform64(0.0, E, u1));
-                e->goal_x[q] = 1.0f; e->goal_y[q] = 5.0f;
-                e->goal2_x[q] = -10.0f; e->goal2_y[q] = 5.0f; /* env.py:361 */
+                e->goal_x[q] = 1.0; e->goal_y[q] = 5.0;
+                e->goal2_x[q] = -10.0; e->goal2_y[q] = 5.0; /* env.py:361 */
             } else if (scenario >= 3 && scenario <= 6) { /* ALAN:175-193, 213-258, 333-357, 377-416 */
                 const double E = (scenario == 3) ? std::sqrt(2 * r * N) * 3
                                : (scenario == 5) ? 3 * r * N : std::sqrt(2 * r * N) * 10;
@@ -995,8 +1104,8 @@ int orc_env_init_scenario(void* env, int32_t scenario) {
                     py = E / 2; gy = g2y = E / 2;
                 }
                 ar.pos[i] = mk((float)px, (float)py);
-                e->goal_x[q] = (float)gx; e->goal_y[q] = (float)gy;
-                e->goal2_x[q] = (float)g2x; e->goal2_y[q] = (float)g2y;
+                e->goal_x[q] = gx; e->goal_y[q] = gy;
+                e->goal2_x[q] = g2x; e->goal2_y[q] = g2y;
             } else {
                 return -1;
             }
@@ -1047,6 +1156,9 @@ static int env_access(Env* e, int field, const void* src, void* dst, size_t byte
         case ORC_FLD_STEP_COUNT: return write ? copy_in(e->step_count, src, bytes) : copy_out(e->step_count, dst, bytes);
         case ORC_FLD_ARENA_DONE: return write ? copy_in(e->arena_done, src, bytes) : copy_out(e->arena_done, dst, bytes);
         case ORC_FLD_EPISODE: return write ? copy_in(e->episode, src, bytes) : copy_out(e->episode, dst, bytes);
+        case ORC_FLD_ALAN_WEIGHTS: return write ? copy_in(e->alan_w, src, bytes) : copy_out(e->alan_w, dst, bytes);
+        case ORC_FLD_ALAN_TIMES: return write ? copy_in(e->alan_t, src, bytes) : copy_out(e->alan_t, dst, bytes);
+        case ORC_FLD_ALAN_ACTION: return write ? copy_in(e->alan_action, src, bytes) : copy_out(e->alan_action, dst, bytes);
         case ORC_FLD_NB_COUNT:
         case ORC_FLD_OBST_COUNT: {
             std::vector<int32_t> tmp((size_t)A * N);
@@ -1133,6 +1245,34 @@ int orc_env_rollout(void* env, int32_t steps, uint32_t flags, int32_t n_threads)
         });
     }
     for (auto& t : th) t.join();
+    return 0;
+}
+
+int orc_env_alan_configure(void* env, const double* actions_xy, int32_t n_actions, double temp, double timewindow,
+                           double time_step) {
+    Env* e = (Env*)env;
+    if (n_actions < 1 || n_actions > 64 || !actions_xy) return -1;
+    e->n_actions = n_actions;
+    e->alan_temp = temp;
+    e->alan_window = timewindow;
+    e->alan_dt = time_step;
+    e->act_c.resize(n_actions); e->act_s.resize(n_actions);
+    for (int k = 0; k < n_actions; ++k) { /* (cos, sin) of atan2(action) = the normalised action */
+        const double x = actions_xy[2 * k], y = actions_xy[2 * k + 1], len = std::sqrt(x * x + y * y);
+        e->act_c[k] = len == 0.0 ? 1.0 : x / len;
+        e->act_s[k] = len == 0.0 ? 0.0 : y / len;
+    }
+    const size_t an = (size_t)e->A() * e->N();
+    e->alan_w.assign(an * n_actions, 0.0);
+    e->alan_t.assign(an * n_actions, 0.0);
+    e->alan_action.assign(an, 0);
+    return 0;
+}
+
+int orc_env_alan_step(void* env, const double* u, uint32_t flags, int32_t prec) {
+    Env* e = (Env*)env;
+    if (e->n_actions <= 0) return -1;
+    for (int a = 0; a < e->A(); ++a) arena_alan_step(*e, a, u ? u + (size_t)a * e->N() : nullptr, flags, prec);
     return 0;
 }
 
@@ -1234,7 +1374,8 @@ void orc_comp_laser_f32(const float* ray_ends, const float* segs, int32_t m, con
 }
 void orc_debug_counters(uint64_t* out4) { for (int i = 0; i < 4; ++i) out4[i] = g_dbg[i]; }
 void orc_sincos64(double a, double* s, double* c) { sincos64(a, s, c); }
-void orc_pref_dir64(float px, float py, float gx, float gy, double* out2) { pref_dir64(px, py, gx, gy, &out2[0], &out2[1]); }
+double orc_exp64(double x) { return exp64(x); }
+void orc_pref_dir64(float px, float py, double gx, double gy, double* out2) { pref_dir64(px, py, gx, gy, &out2[0], &out2[1]); }
 void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out4) {
     philox4x32(c0, c1, c2, c3, k0, k1, out4);
 }

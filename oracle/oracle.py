@@ -21,7 +21,7 @@ SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN
 (FLD_POS_X, FLD_POS_Y, FLD_VEL_X, FLD_VEL_Y, FLD_PREF_X, FLD_PREF_Y, FLD_GOAL_X, FLD_GOAL_Y,
  FLD_GOAL2_X, FLD_GOAL2_Y, FLD_REWARD, FLD_AGENT_DONE, FLD_ARRIVE_STEP, FLD_NB_COUNT, FLD_NB_IDX,
  FLD_OBST_COUNT, FLD_OBST_IDX, FLD_OBS, FLD_OBS64, FLD_REWARD64, FLD_STEP_COUNT, FLD_ARENA_DONE,
- FLD_EPISODE, FLD_REGOAL_COUNT) = range(24)
+ FLD_EPISODE, FLD_REGOAL_COUNT, FLD_ALAN_WEIGHTS, FLD_ALAN_TIMES, FLD_ALAN_ACTION) = range(27)
 
 
 class Config(C.Structure):
@@ -78,6 +78,10 @@ def lib():
     L.orc_env_orca_step.argtypes = [vp, u32, i32]
     L.orc_env_rollout.argtypes = [vp, i32, u32, i32]
     L.orc_env_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.orc_env_alan_configure.argtypes = [vp, vp, i32, C.c_double, C.c_double, C.c_double]
+    L.orc_env_alan_step.argtypes = [vp, vp, u32, i32]
+    L.orc_exp64.argtypes = [C.c_double]
+    L.orc_exp64.restype = C.c_double
     L.orc_env_obstacle_table.argtypes = [vp] + [vp] * 7 + [i32]
     L.orc_sim_create.restype = vp
     L.orc_sim_create.argtypes = [f32, f32, i32, f32, f32, f32, f32, f32, f32]
@@ -100,7 +104,7 @@ def lib():
     L.orc_comp_laser_f64.argtypes = [vp, vp, i32, vp, vp]
     L.orc_comp_laser_f32.argtypes = [vp, vp, i32, vp, vp]
     L.orc_sincos64.argtypes = [C.c_double, vp, vp]
-    L.orc_pref_dir64.argtypes = [f32, f32, f32, f32, vp]
+    L.orc_pref_dir64.argtypes = [f32, f32, C.c_double, C.c_double, vp]
     L.orc_philox4x32.argtypes = [u32] * 6 + [vp]
     L.orc_ray_table.argtypes = [C.c_double, vp]
     L.orc_octagon_table.argtypes = [C.c_double, vp]
@@ -128,7 +132,10 @@ _FIELD_SHAPES = {
     FLD_OBS64: (OBS_DIM, np.float64), FLD_REWARD64: (None, np.float64),
     FLD_AGENT_DONE: (None, np.int32), FLD_ARRIVE_STEP: (None, np.int32),
     FLD_NB_COUNT: (None, np.int32), FLD_OBST_COUNT: (None, np.int32),
-    FLD_REGOAL_COUNT: (None, np.int32),
+    FLD_REGOAL_COUNT: (None, np.int32), FLD_ALAN_ACTION: (None, np.int32),
+    FLD_GOAL_X: (None, np.float64), FLD_GOAL_Y: (None, np.float64), FLD_GOAL2_X: (None, np.float64),
+    FLD_GOAL2_Y: (None, np.float64),
+    FLD_ALAN_WEIGHTS: ("nA", np.float64), FLD_ALAN_TIMES: ("nA", np.float64),
 }
 _ARENA_FIELDS = (FLD_STEP_COUNT, FLD_ARENA_DONE, FLD_EPISODE)
 
@@ -155,6 +162,8 @@ class OracleEnv:
             last = self.cfg.max_neighbors
         elif last == "S":
             last = self.cfg.max_obst_neighbors
+        elif last == "nA":
+            last = self.n_actions
         return ((self.A, self.N) if last is None else (self.A, self.N, last)), dt
 
     def set_obstacles(self, polys):
@@ -205,6 +214,18 @@ class OracleEnv:
 
     def rollout(self, steps, flags=0, n_threads=1):
         assert self.L.orc_env_rollout(self.h, steps, flags, n_threads) == 0
+
+    def alan_configure(self, actions, temp=0.2, timewindow=2.0, time_step=1 / 60.):
+        a = np.ascontiguousarray(np.asarray(actions, np.float64).reshape(-1, 2))
+        self.n_actions = a.shape[0]
+        assert self.L.orc_env_alan_configure(self.h, _ptr(a), a.shape[0], temp, timewindow, time_step) == 0
+
+    def alan_step(self, u=None, flags=0, prec=PREC_F32):
+        if u is None:
+            assert self.L.orc_env_alan_step(self.h, None, flags, prec) == 0
+        else:
+            uu = np.ascontiguousarray(np.asarray(u, np.float64).reshape(self.A, self.N))
+            assert self.L.orc_env_alan_step(self.h, _ptr(uu), flags, prec) == 0
 
     def stats(self):
         s = Stats()
@@ -263,6 +284,10 @@ def sincos64(a):
     s, c = C.c_double(), C.c_double()
     lib().orc_sincos64(float(a), C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def exp64(x):
+    return lib().orc_exp64(float(x))
 
 
 def pref_dir64(px, py, gx, gy):

@@ -11,7 +11,8 @@ none of its source is copied: the fixtures hold inputs and the outputs the refer
                       by oracle/rvo2_shim.py (the oracle's ORCA), `gym`, `ray`, `tkinter` stubbed,
                       time.clock/time.sleep shimmed and random.uniform replaced by a seeded
                       stream.  Pins the env loop A5-A9, A16-A19.
-  alan_scenarios.npz  ALAN_true.py scenario generators (circle, crowd) start/goal layouts.
+  alan_scenarios.npz  ALAN_true.py scenario generators: start/goal layouts and obstacle polygons.
+  alan_online.npz     ALAN_true.py online_step runs (softmax selection, weights, arrival times, TTime).
 
 Usage: python tests/golden/make_golden.py
 """
@@ -282,6 +283,78 @@ def gen_alan_scenarios():
     print("alan_scenarios.npz:", len(out), "arrays for", [c[0] + str(c[1]) for c in cases])
 
 
+def gen_alan_online():
+    """ALAN_true.py online_step (softmax action selection + bandit update, :569-628) and the run_sim
+    bookkeeping (:119-131) driven for a few hundred steps; np.random.choice is replaced by a
+    recording re-implementation of numpy's own draw (cdf = cumsum(p); cdf /= cdf[-1];
+    searchsorted(u, side='right')) fed from a seeded uniform stream."""
+    import warnings
+    warnings.simplefilter("ignore")
+    import collision_avoidance.ALAN.ALAN_true as alan
+    real_choice = np.random.choice
+    out = {}
+    cases = (("crowd", 12, None, 360), ("circle", 8, [(1, 0), (-0.946001067452245, -0.3241635087100537),
+                                                      (0.9651519613079926, -0.2616900677964968)], 300),
+             ("deadlock", 10, [(1, 0), (-0.8507885983503763, -0.5255080978605392)], 260),
+             ("crowd", 9, [(1, 0), (0.06130798855686512, -0.9981188959934139), (0.6957331792402002, -0.718300315539624),
+                           (0.2199481143650689, 0.9755115719391804), (-0.34342388205007957, -0.9391805136594631),
+                           (-0.5032837686361407, -0.8641211999641044), (0.23892114215448593, 0.9710389733844857),
+                           (-0.9579667593692613, -0.28687922187491344), (-0.6767380373137093, 0.7362238985884584)], 200))
+    for ci, (scen, n, actions, steps) in enumerate(cases):
+        alan.uniform = _Stream(500 + ci)
+        urng = np.random.RandomState(900 + ci)
+        drawn = []
+
+        def choice(a, size=None, p=None):
+            cdf = np.asarray(p, np.float64).cumsum()
+            cdf /= cdf[-1]
+            u = urng.random_sample()
+            drawn.append(u)
+            return np.array([cdf.searchsorted(u, side='right')])
+        np.random.choice = choice
+        try:
+            sim = alan.Collision_Avoidance_Sim(numAgents=n, scenario=scen, online_actions=actions, visualize=False)
+            sim.reset(actions)   # the constructor zeroes min_TTime after computing it (:71); reset() keeps it
+            key = "c%d_" % ci
+            nA = len(sim.online_actions)
+            out[key + "scenario"] = np.array(scen)
+            out[key + "actions"] = np.array(sim.online_actions, np.float64)
+            out[key + "pos0"] = np.array([sim.sim.getAgentPosition(i) for i in range(n)], np.float32)
+            out[key + "vel0"] = np.array([sim.sim.getAgentVelocity(i) for i in range(n)], np.float32)
+            out[key + "goal0"] = np.array([sim.world["targets_pos"][i][0] for i in range(n)], np.float64)
+            out[key + "goal20"] = np.array([sim.world["targets_pos"][i][1] for i in range(n)], np.float64)
+            rec = dict(u=[], pos=[], vel=[], w=[], t=[], done=[], times=[])
+            for s_ in range(steps):
+                del drawn[:]
+                sim.online_step()
+                sim.step_count += 1
+                sim.done_test()
+                rec["u"].append(list(drawn))
+                rec["pos"].append([sim.sim.getAgentPosition(i) for i in range(n)])
+                rec["vel"].append([sim.sim.getAgentVelocity(i) for i in range(n)])
+                rec["w"].append(np.array(sim.world["action_weights"], np.float64))
+                rec["t"].append(np.array(sim.world["action_times"], np.float64))
+                rec["done"].append(list(sim.agents_done))
+                rec["times"].append(list(sim.agents_time))
+            out[key + "u"] = np.array(rec["u"], np.float64)
+            out[key + "pos"] = np.array(rec["pos"], np.float32)
+            out[key + "vel"] = np.array(rec["vel"], np.float32)
+            out[key + "w"] = np.array(rec["w"], np.float64)[::10]          # every 10th step
+            out[key + "t"] = np.array(rec["t"], np.float64)[::10]
+            out[key + "w_last"] = np.array(rec["w"][-1], np.float64)
+            out[key + "done"] = np.array(rec["done"], np.int32)
+            out[key + "agents_time"] = np.array(rec["times"][-1], np.float64)
+            times = np.array(sim.agents_time)
+            out[key + "TTime"] = np.float64(np.average(times) + 3 * np.std(times, 0))   # ALAN:127-130
+            out[key + "min_TTime"] = np.float64(sim.min_TTime)
+            out[key + "max_step"] = np.int32(sim.max_step)
+        finally:
+            np.random.choice = real_choice
+    out["n_cases"] = np.int32(len(cases))
+    np.savez_compressed(os.path.join(HERE, "alan_online.npz"), **out)
+    print("alan_online.npz: %d cases, done counts %s" % (len(cases), [int(out["c%d_done" % i][-1].sum()) for i in range(len(cases))]))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
@@ -292,3 +365,4 @@ if __name__ == "__main__":
     gen_env_fixture("env_doorway_n6_dense.npz", 6, seed=11, n_steps=260, reset_at=(130,), obs_every=4,
                     spawn_squeeze={(5.0, 10): (0.0, 0.25), (0, 10): (0.3, 0.7)})
     gen_alan_scenarios()
+    gen_alan_online()

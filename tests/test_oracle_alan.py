@@ -1,0 +1,80 @@
+"""The oracle's ALAN online step against runs of the reference's own online_step
+(tests/golden/alan_online.npz): action draws, trajectories, bandit weights, arrival times, TTime."""
+import os
+
+import numpy as np
+import pytest
+
+from collision_avoidance_amd import scenarios
+from oracle import oracle as o
+
+
+def load_case(golden_dir, ci):
+    g = np.load(os.path.join(golden_dir, "alan_online.npz"))
+    key = "c%d_" % ci
+    return {k[len(key):]: g[k] for k in g.files if k.startswith(key)}
+
+
+def setup_env(make_env, c, set_field, F):
+    """Common initial state for oracle and GPU replays."""
+    scen = str(c["scenario"])
+    n = c["pos0"].shape[0]
+    p = scenarios.alan_params(n, scen)
+    env = make_env(n, scen, p)
+    for f, v in ((F.FLD_POS_X, c["pos0"][:, 0]), (F.FLD_POS_Y, c["pos0"][:, 1]), (F.FLD_VEL_X, c["vel0"][:, 0]),
+                 (F.FLD_VEL_Y, c["vel0"][:, 1]), (F.FLD_GOAL_X, c["goal0"][:, 0]), (F.FLD_GOAL_Y, c["goal0"][:, 1]),
+                 (F.FLD_GOAL2_X, c["goal20"][:, 0]), (F.FLD_GOAL2_Y, c["goal20"][:, 1])):
+        set_field(env, f, v)
+    return env, n, p
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_online_step_matches_reference(golden_dir, ci):
+    c = load_case(golden_dir, ci)
+
+    def make(n, scen, p):
+        e = o.OracleEnv(o.make_config(n_arenas=1, n_agents=n, max_obst_neighbors=8, **p))
+        e.set_obstacles(scenarios.obstacles(scen, n))
+        e.init_scenario(scenarios.SCENARIO_IDS[scen])
+        return e
+    env, n, p = setup_env(make, c, lambda e, f, v: e.set(f, v), o)
+    env.alan_configure(c["actions"])
+    assert p["max_step"] == int(c["max_step"])
+    steps = c["u"].shape[0]
+    for s in range(steps):
+        env.alan_step(c["u"][s], prec=o.PREC_F64)
+        np.testing.assert_array_equal(env.get(o.FLD_POS_X)[0], c["pos"][s][:, 0], err_msg="step %d" % s)
+        np.testing.assert_array_equal(env.get(o.FLD_POS_Y)[0], c["pos"][s][:, 1])
+        np.testing.assert_array_equal(env.get(o.FLD_VEL_X)[0], c["vel"][s][:, 0])
+        np.testing.assert_array_equal(env.get(o.FLD_AGENT_DONE)[0], c["done"][s])
+        if s % 10 == 0:
+            np.testing.assert_allclose(env.get(o.FLD_ALAN_WEIGHTS)[0], c["w"][s // 10], rtol=0, atol=1e-13)
+            np.testing.assert_array_equal(env.get(o.FLD_ALAN_TIMES)[0], c["t"][s // 10])   # same fp64 additions
+    np.testing.assert_allclose(env.get(o.FLD_ALAN_WEIGHTS)[0], c["w_last"], rtol=0, atol=1e-13)
+    # arrival times and TTime (ALAN_true.py:125-131, 559)
+    from collision_avoidance_amd import alan
+    arrive = env.get(o.FLD_ARRIVE_STEP)[0]
+    times = alan.agents_time(arrive, env.get(o.FLD_AGENT_DONE)[0], p["time_step"], p["max_step"])
+    np.testing.assert_allclose(times, c["agents_time"], rtol=0, atol=1e-12)
+    assert abs(alan.ttime(times) - float(c["TTime"])) < 1e-12
+    assert abs(alan.min_ttime(c["pos0"], c["goal0"], p["max_speed"]) - float(c["min_TTime"])) < 1e-12
+
+
+def test_softmax_draw_pieces():
+    for x in np.linspace(-6, 6, 2001):
+        assert abs(o.exp64(x) - np.exp(x)) <= 3e-16 * np.exp(x)
+    # counter-based stream when no uniforms are injected: deterministic and shard-invariant
+    n = 8
+    p = scenarios.alan_params(n, "crowd")
+    acts = [(1, 0), (0, 1), (-1, 0), (0, -1)]
+
+    def run(A, off):
+        e = o.OracleEnv(o.make_config(n_arenas=A, n_agents=n, seed=5, arena_offset=off, **p))
+        e.set_obstacles(scenarios.obstacles("crowd", n)); e.init_scenario(o.SCN_CROWD); e.alan_configure(acts)
+        for _ in range(50):
+            e.alan_step()
+        return e.get(o.FLD_POS_X), e.get(o.FLD_ALAN_ACTION)
+    px, act = run(3, 0)
+    px2, act2 = run(1, 2)
+    np.testing.assert_array_equal(px[2], px2[0]); np.testing.assert_array_equal(act[2], act2[0])
+    assert len(np.unique(act)) > 1

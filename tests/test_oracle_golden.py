@@ -125,8 +125,8 @@ def test_alan_scenarios_match_reference(golden_dir):
             np.testing.assert_array_equal(env.get(o.FLD_POS_X)[a], g[key + "pos"][:, 0], err_msg=key)
             np.testing.assert_array_equal(env.get(o.FLD_POS_Y)[a], g[key + "pos"][:, 1], err_msg=key)
             for fx, fy, name in ((o.FLD_GOAL_X, o.FLD_GOAL_Y, "goal"), (o.FLD_GOAL2_X, o.FLD_GOAL2_Y, "goal2")):
-                np.testing.assert_array_equal(env.get(fx)[a], g[key + name][:, 0].astype(np.float32), err_msg=key + name)
-                np.testing.assert_array_equal(env.get(fy)[a], g[key + name][:, 1].astype(np.float32), err_msg=key + name)
+                np.testing.assert_array_equal(env.get(fx)[a], g[key + name][:, 0], err_msg=key + name)   # fp64, exact
+                np.testing.assert_array_equal(env.get(fy)[a], g[key + name][:, 1], err_msg=key + name)
         if scen != "blocks":
             polys = np.array(scenarios.obstacles(scen, n), np.float64).astype(np.float32)
             np.testing.assert_array_equal(polys, g[key + "obst"], err_msg=key + "obst")
@@ -143,8 +143,8 @@ def test_alan_scenarios_match_reference(golden_dir):
         assert g[key + "pos"][:, 0].min() >= x0 - 1e-6
         np.testing.assert_array_equal(np.array(scenarios.obstacles(scen, n), np.float64).astype(np.float32), g[key + "obst"])
         if scen == "congested":
-            np.testing.assert_array_equal(env.get(o.FLD_GOAL_X)[0], g[key + "goal"][:, 0].astype(np.float32))
-            np.testing.assert_array_equal(env.get(o.FLD_GOAL2_X)[0], g[key + "goal2"][:, 0].astype(np.float32))
+            np.testing.assert_array_equal(env.get(o.FLD_GOAL_X)[0], g[key + "goal"][:, 0])
+            np.testing.assert_array_equal(env.get(o.FLD_GOAL2_X)[0], g[key + "goal2"][:, 0])
     blk = np.array(scenarios.obstacles("blocks", 12, seed=5), np.float64)
     e = scenarios.envsize("blocks", 12)
     np.testing.assert_array_equal(blk[0].astype(np.float32), g["blocks12_obst"][0])      # the border
