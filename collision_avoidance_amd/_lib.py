@@ -11,17 +11,18 @@ from . import build as _build
 OBS_DIM = 64
 MAX_NEIGHBORS, MAX_OBST_NEIGHBORS, MAX_AGENTS = 16, 8, 1024
 DONE_XLESS, DONE_GOAL, DONE_REGOAL = 0, 1, 2
-F_OBS, F_STATS, F_AUTORESET, F_NODONE = 1, 2, 4, 8
+F_OBS, F_STATS, F_AUTORESET, F_NODONE, F_FREEZE = 1, 2, 4, 8, 16
 SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN_DEADLOCK = range(7)
 
 (FLD_POS_X, FLD_POS_Y, FLD_VEL_X, FLD_VEL_Y, FLD_PREF_X, FLD_PREF_Y, FLD_GOAL_X, FLD_GOAL_Y,
  FLD_GOAL2_X, FLD_GOAL2_Y, FLD_REWARD, FLD_AGENT_DONE, FLD_ARRIVE_STEP, FLD_NB_COUNT, FLD_NB_IDX,
  FLD_OBST_COUNT, FLD_OBST_IDX, FLD_OBS, FLD_STEP_COUNT, FLD_ARENA_DONE, FLD_EPISODE,
- FLD_REGOAL_COUNT) = range(22)
+ FLD_REGOAL_COUNT, FLD_ALAN_WEIGHTS, FLD_ALAN_TIMES, FLD_ALAN_ACTION) = range(25)
 
 EXPORTS = ("ca_create", "ca_destroy", "ca_last_error", "ca_set_stream", "ca_set_obstacles", "ca_init_scenario", "ca_set",
            "ca_get", "ca_field_ptr", "ca_bind_obs", "ca_reset", "ca_step", "ca_step_host", "ca_orca_step", "ca_observe", "ca_rollout",
-           "ca_get_stats", "ca_reset_stats", "ca_sync", "ca_debug_math", "ca_profile", "ca_profile_read", "ca_launch_info")
+           "ca_get_stats", "ca_reset_stats", "ca_sync", "ca_debug_math", "ca_profile", "ca_profile_read", "ca_launch_info",
+           "ca_alan_configure", "ca_alan_step", "ca_alan_rollout")
 
 
 class Config(C.Structure):
@@ -84,6 +85,9 @@ def load():
     L.ca_orca_step.argtypes = [vp, u32]
     L.ca_observe.argtypes = [vp]
     L.ca_rollout.argtypes = [vp, i32, u32]
+    L.ca_alan_configure.argtypes = [vp, vp, i32, C.c_double, C.c_double, C.c_double]
+    L.ca_alan_step.argtypes = [vp, vp, i32, u32]
+    L.ca_alan_rollout.argtypes = [vp, i32, u32]
     L.ca_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.ca_reset_stats.argtypes = [vp]
     L.ca_sync.argtypes = [vp]

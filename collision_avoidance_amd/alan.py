@@ -34,15 +34,21 @@ def min_ttime(start_xy, goal_xy, max_speed=1.0):
 
 
 class Collision_Avoidance_Sim(object):
-    """Same constructor and run_sim()/reset() contract as ALAN_true.py:10-131 (no Tk window)."""
+    """Same constructor and run_sim()/reset() contract as ALAN_true.py:10-131 (no Tk window).
 
-    def __init__(self, numAgents=50, scenario="crowd", online_actions=None, visualize=False, device=0, seed=0):
+    n_arenas > 1 runs that many independent episodes of the scenario side by side (arena g of a handle
+    is keyed by (seed, g)); run_sim() then returns arrays with one entry per arena."""
+
+    POLL = 256   # steps enqueued between two looks at the arena_done flags
+
+    def __init__(self, numAgents=50, scenario="crowd", online_actions=None, visualize=False, device=0, seed=0,
+                 n_arenas=1):
         self.numAgents, self.scenario = numAgents, scenario
         self.timeStep, self.maxSpeed, self.radius = 1 / 60., 1, 0.5
         self.gamma, self.timewindow, self.online_temp = 0.6, 2, 0.2                # ALAN_true.py:47-49
         self.default_online_actions = list(DEFAULT_ACTIONS)
         self.max_step = int((10 / self.timeStep) * numAgents)                       # ALAN_true.py:59
-        self._device, self._seed = device, seed
+        self._device, self._seed, self.n_arenas = device, seed, int(n_arenas)
         self.vec = None
         self.reset(online_actions)
 
@@ -54,34 +60,41 @@ class Collision_Avoidance_Sim(object):
             self.vec.close()
         p = scenarios.alan_params(self.numAgents, self.scenario)
         self.envsize = scenarios.envsize(self.scenario, self.numAgents)
-        self.vec = VecCollisionAvoidanceEnv(1, self.numAgents, scenario=self.scenario, params=p,
+        self.vec = VecCollisionAvoidanceEnv(self.n_arenas, self.numAgents, scenario=self.scenario, params=p,
                                             device=self._device, seed=self._seed, use_torch=False)
-        self.vec.alan_configure(self.online_actions, self.online_temp, self.timewindow)
+        self.vec.alan_configure(self.online_actions, self.online_temp, self.timewindow, self.timeStep)
         self.step_count, self.TTime = 0, 0
-        start = np.stack([self.vec.get(_lib.FLD_POS_X)[0], self.vec.get(_lib.FLD_POS_Y)[0]], 1)
-        goal = np.stack([self.vec.get(_lib.FLD_GOAL_X)[0], self.vec.get(_lib.FLD_GOAL_Y)[0]], 1)
-        self.min_TTime = min_ttime(start, goal, self.maxSpeed)
+        start = np.stack([self.vec.get(_lib.FLD_POS_X), self.vec.get(_lib.FLD_POS_Y)], -1)
+        goal = np.stack([self.vec.get(_lib.FLD_GOAL_X), self.vec.get(_lib.FLD_GOAL_Y)], -1)
+        self._min_ttimes = np.array([min_ttime(start[a], goal[a], self.maxSpeed) for a in range(self.n_arenas)])
+        self.min_TTime = float(self._min_ttimes[0])
 
     def run_sim(self, mode=1):
         """mode 1: ALAN online learning, 0: plain ORCA (ALAN_true.py:106-131).
-        Returns (success, total_time, TTime, min_TTime)."""
+        Returns (success, total_time, TTime, min_TTime); arrays of length n_arenas when n_arenas > 1.
+        Every arena stops at its own last arrival (or at max_step) on the device, like the `break` at
+        ALAN_true.py:121-123; the host only looks at the flags every POLL steps."""
         from . import _lib
-        success = False
-        for _ in range(self.max_step):
+        left = self.max_step - self.step_count
+        while left > 0:
+            n = min(self.POLL, left)
             if mode == 0:
-                self.vec.orca_step()
+                self.vec.rollout(n, freeze=True)
             else:
-                self.vec.alan_step()
-            self.step_count += 1
-            poll = self.step_count % 16 == 0 or self.step_count == self.max_step
-            if poll and int(self.vec.get(_lib.FLD_ARENA_DONE)[0]):
-                success = bool(self.vec.get(_lib.FLD_AGENT_DONE)[0].all())
+                self.vec.alan_rollout(n, freeze=True)
+            left -= n
+            if self.vec.get(_lib.FLD_ARENA_DONE).all():
                 break
-        done = self.vec.get(_lib.FLD_AGENT_DONE)[0]
-        self.agents_done = [int(d) for d in done]
-        self.agents_time = list(agents_time(self.vec.get(_lib.FLD_ARRIVE_STEP)[0], done, self.timeStep, self.max_step))
-        success = bool(done.all())
-        # the device keeps stepping finished agents between polls; the episode length is the last arrival
-        total_steps = int(self.vec.get(_lib.FLD_ARRIVE_STEP)[0].max()) if success else self.step_count
-        self.TTime = ttime(self.agents_time)
-        return success, total_steps * self.timeStep, self.TTime, self.min_TTime
+        steps = self.vec.get(_lib.FLD_STEP_COUNT)
+        done = self.vec.get(_lib.FLD_AGENT_DONE)
+        arrive = self.vec.get(_lib.FLD_ARRIVE_STEP)
+        self.step_count = int(steps[0])
+        self.agents_done = [int(d) for d in done[0]]
+        times = agents_time(arrive, done, self.timeStep, self.max_step)
+        self.agents_time = list(times[0])
+        success = done.all(axis=1)
+        ttimes = np.array([ttime(times[a]) for a in range(self.n_arenas)])
+        self.TTime = float(ttimes[0])
+        if self.n_arenas == 1:
+            return bool(success[0]), self.step_count * self.timeStep, self.TTime, self.min_TTime
+        return success, steps * self.timeStep, ttimes, self._min_ttimes

@@ -36,6 +36,13 @@ struct ca_env {
     unsigned long long* dbg = nullptr;  // CA_STAMPS diagnostic build only
     unsigned long long* dbg_obs = nullptr;
     float *tmp_x = nullptr, *tmp_y = nullptr;  // staging for explicit reset positions / host actions
+    // ALAN online learning (ca_alan_configure): [A*N][n_actions] fp64 weights / times, [A*N] action,
+    // [A*N][4] fp64 directions of the step in flight
+    double *alan_w = nullptr, *alan_t = nullptr, *alan_dirs = nullptr, *alan_u = nullptr;
+    int* alan_action = nullptr;
+    int n_actions = 0;
+    double act_c[CA_ALAN_MAX_ACTIONS], act_s[CA_ALAN_MAX_ACTIONS];
+    double alan_temp = 0.2, alan_window = 2.0, alan_dt = 1.0 / 60.0;
     ObstDev* d_obst = nullptr;
     std::vector<ObstDev> h_obst;
     int P = 1, logP = 0, BS = 64, grid = 1, K = 0, S = 1;
@@ -70,7 +77,7 @@ static int fail(ca_env* e, int code, const char* fmt, ...) {
         if (_r != hipSuccess) return fail(e, CA_EHIP, "%s failed: %s", #call, hipGetErrorString(_r)); \
     } while (0)
 
-enum { KIND_NBR = 0, KIND_STEP = 1, KIND_OBS = 2, KIND_RESET = 3 };
+enum { KIND_NBR = 0, KIND_STEP = 1, KIND_OBS = 2, KIND_RESET = 3 };  // KIND_RESET also times the small ALAN kernels
 static hipEvent_t prof_event(ca_env* e) {
     if (!e->free_events.empty()) { hipEvent_t ev = e->free_events.back(); e->free_events.pop_back(); return ev; }
     hipEvent_t ev = nullptr;
@@ -123,6 +130,9 @@ static FieldInfo field_info(ca_env* e, int f) {
         case CA_FLD_ARENA_DONE: return {e->arena_done, A * 4, true};
         case CA_FLD_EPISODE: return {e->episode, A * 4, true};
         case CA_FLD_REGOAL_COUNT: return {e->regoal_count, an * 4, true};
+        case CA_FLD_ALAN_WEIGHTS: return {e->alan_w, an * 8 * (size_t)e->n_actions, true};
+        case CA_FLD_ALAN_TIMES: return {e->alan_t, an * 8 * (size_t)e->n_actions, true};
+        case CA_FLD_ALAN_ACTION: return {e->alan_action, an * 4, false};
         default: return {nullptr, 0, false};
     }
 }
@@ -362,7 +372,8 @@ int ca_destroy(ca_env* e) {
                     e->goal2_x, e->goal2_y, e->reward, e->tmp_x, e->tmp_y, e->orient_x, e->orient_y,
                     e->agent_done, e->arrive_step,
                     e->regoal_count, e->nb_count, e->nb_idx, e->obst_count, e->obst_idx, e->step_count,
-                    e->arena_done, e->episode, e->arena_stats, e->d_obst, e->dbg, e->dbg_obs};
+                    e->arena_done, e->episode, e->arena_stats, e->d_obst, e->dbg, e->dbg_obs,
+                    e->alan_w, e->alan_t, e->alan_dirs, e->alan_u, e->alan_action};
     for (void* b : bufs) if (b) hipFree(b);
     if (e->obs && !e->obs_external) hipFree(e->obs);
     for (const ca_env::Span& sp : e->spans) { hipEventDestroy(sp.t0); hipEventDestroy(sp.t1); }
@@ -638,6 +649,86 @@ int ca_orca_step(ca_env* e, uint32_t flags) {
     return do_step(e, nullptr, flags);
 }
 
+int ca_alan_configure(ca_env* e, const double* actions_xy, int32_t n_actions, double temp, double timewindow,
+                      double time_step) {
+    if (!e || !actions_xy) return fail(e, CA_EINVAL, "ca_alan_configure: null argument");
+    if (n_actions < 1 || n_actions > CA_ALAN_MAX_ACTIONS)
+        return fail(e, CA_ERANGE, "ca_alan_configure: n_actions=%d out of range 1..%d", n_actions, CA_ALAN_MAX_ACTIONS);
+    if (!(temp > 0.0) || !(timewindow > 0.0) || !(time_step > 0.0))
+        return fail(e, CA_EINVAL, "ca_alan_configure: temp, timewindow and time_step must be positive");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (double** b : {&e->alan_w, &e->alan_t, &e->alan_dirs, &e->alan_u}) { if (*b) hipFree(*b); *b = nullptr; }
+    if (e->alan_action) { hipFree(e->alan_action); e->alan_action = nullptr; }
+    e->n_actions = 0;
+    const size_t an = AN(e);
+    HIPCHK(e, dalloc(&e->alan_w, an * (size_t)n_actions));
+    HIPCHK(e, dalloc(&e->alan_t, an * (size_t)n_actions));
+    HIPCHK(e, dalloc(&e->alan_dirs, an * 4));
+    HIPCHK(e, dalloc(&e->alan_u, an));
+    HIPCHK(e, dalloc(&e->alan_action, an));
+    for (int k = 0; k < n_actions; ++k) {  // (cos, sin) of atan2(y, x) = the normalised vector (ALAN:592-595)
+        const double x = actions_xy[2 * k], y = actions_xy[2 * k + 1], len = std::sqrt(x * x + y * y);
+        e->act_c[k] = len == 0.0 ? 1.0 : x / len;
+        e->act_s[k] = len == 0.0 ? 0.0 : y / len;
+    }
+    e->n_actions = n_actions;
+    e->alan_temp = temp; e->alan_window = timewindow; e->alan_dt = time_step;
+    return CA_OK;
+}
+
+int ca_alan_step(ca_env* e, const double* u, int32_t u_is_device, uint32_t flags) {
+    if (!e) return CA_EINVAL;
+    if (e->n_actions <= 0) return fail(e, CA_EINVAL, "ca_alan_step: call ca_alan_configure first");
+    if (flags & (CA_F_AUTORESET | CA_F_NODONE))
+        return fail(e, CA_EINVAL, "ca_alan_step: CA_F_AUTORESET / CA_F_NODONE do not apply (ALAN:106-123)");
+    HIPCHK(e, hipSetDevice(e->device));
+    if (u && !u_is_device) {  // stage the caller's host uniforms
+        HIPCHK(e, hipMemcpyAsync(e->alan_u, u, AN(e) * 8, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        u = e->alan_u;
+    }
+    if (e->prof_period > 1) e->profiling = (e->steps_done % (uint64_t)e->prof_period) == 0;
+    const ca_config& c = e->cfg;
+    AlanArgs p;
+    p.pos_x = e->pos_x; p.pos_y = e->pos_y; p.vel_x = e->vel_x; p.vel_y = e->vel_y;
+    p.goal_x = e->goal_x; p.goal_y = e->goal_y; p.pref_x = e->pref_x; p.pref_y = e->pref_y; p.reward = e->reward;
+    p.w = e->alan_w; p.t = e->alan_t; p.action = e->alan_action; p.dirs = e->alan_dirs; p.u = u;
+    p.step_count = e->step_count; p.arena_done = e->arena_done; p.arena_stats = e->arena_stats;
+    memcpy(p.act_c, e->act_c, sizeof p.act_c);
+    memcpy(p.act_s, e->act_s, sizeof p.act_s);
+    p.temp = e->alan_temp; p.window = e->alan_window; p.dt = e->alan_dt; p.reward_scale = c.reward_scale;
+    p.seed = c.seed; p.arena_offset = c.arena_offset; p.A = c.n_arenas; p.N = c.n_agents; p.nA = e->n_actions;
+    p.flags = flags;
+    const dim3 grid((unsigned)((AN(e) + ALAN_BS - 1) / ALAN_BS)), block(ALAN_BS);
+    {
+        ProfScope ps(e, KIND_RESET);
+        hipLaunchKernelGGL(alan_select_kernel, grid, block, 0, e->stream, p);
+    }
+    HIPCHK(e, hipGetLastError());
+    StepArgs a;
+    fill_args(e, a, nullptr, flags);  // sim.doStep() + ALAN:118-121 = the ORCA-mode step
+    HIPCHK(e, launch_step(e, a));
+    {
+        ProfScope ps(e, KIND_RESET);
+        hipLaunchKernelGGL(alan_update_kernel, grid, block, 0, e->stream, p);
+    }
+    HIPCHK(e, hipGetLastError());
+    e->orient_valid = true;
+    if (flags & CA_F_OBS) HIPCHK(e, launch_obs(e));
+    e->steps_done += 1;
+    return CA_OK;
+}
+
+int ca_alan_rollout(ca_env* e, int32_t steps, uint32_t flags) {
+    if (!e || steps < 0) return fail(e, CA_EINVAL, "ca_alan_rollout: bad argument");
+    for (int s = 0; s < steps; ++s) {
+        const int rc = ca_alan_step(e, nullptr, 0, flags);
+        if (rc) return rc;
+    }
+    return CA_OK;
+}
+
 int ca_observe(ca_env* e) {
     if (!e) return CA_EINVAL;
     HIPCHK(e, hipSetDevice(e->device));
@@ -671,6 +762,7 @@ int ca_get_stats(ca_env* e, ca_stats* out) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     ca_stats s;
     memset(&s, 0, sizeof s);
+    unsigned long long frozen = 0;  // arena-steps skipped under CA_F_FREEZE
     for (size_t a = 0; a < A; ++a) {
         const unsigned long long* r = &h[a * ST_STRIDE];
         s.episodes += r[ST_EPISODES]; s.collisions += r[ST_COLL]; s.obst_collisions += r[ST_OBST_COLL];
@@ -678,8 +770,9 @@ int ca_get_stats(ca_env* e, ca_stats* out) {
         double d;
         memcpy(&d, &r[ST_SUMREW], 8);
         s.sum_reward += d;
+        frozen += r[ST_FROZEN];
     }
-    s.agent_steps = e->steps_done * (uint64_t)AN(e);
+    s.agent_steps = (e->steps_done * (uint64_t)e->cfg.n_arenas - frozen) * (uint64_t)e->cfg.n_agents;
     *out = s;
     return CA_OK;
 }
@@ -693,8 +786,8 @@ int ca_reset_stats(ca_env* e) {
 }
 
 int ca_debug_math(ca_env* e, int32_t op, const void* in, void* out, int32_t n) {
-    if (!e || !in || !out || n <= 0 || op < 0 || op > 4) return fail(e, CA_EINVAL, "ca_debug_math: bad argument");
-    static const size_t in_b[] = {4, 8, 8, 16, 16}, out_b[] = {4, 4, 16, 16, 16};
+    if (!e || !in || !out || n <= 0 || op < 0 || op > 5) return fail(e, CA_EINVAL, "ca_debug_math: bad argument");
+    static const size_t in_b[] = {4, 8, 8, 16, 16, 8}, out_b[] = {4, 4, 16, 16, 16, 8};
     HIPCHK(e, hipSetDevice(e->device));
     void *di = nullptr, *dout = nullptr;
     HIPCHK(e, hipMalloc(&di, in_b[op] * n));

@@ -58,6 +58,31 @@ CA_HD void sincos64(double a, double* s, double* c) {
     *c = (q == 0) ? cp : (q == 1) ? -sp : (q == 2) ? -cp : sp;
 }
 
+// ---- e^x in fp64: k = round(x/ln2), r = x - k ln2 in two parts, degree-13 Taylor polynomial in
+// Horner form, exact scaling by 2^k (|x| <~ 700, error <~ 2e-16 relative) ----
+CA_HD double exp64(double x) {
+    const double kd = floor(x * 1.44269504088896338700e+00 + 0.5);
+    const double r = (x - kd * 6.93147180369123816490e-01) - kd * 1.90821492927058770002e-10;
+    double pl = 1.0 / 6227020800.0;
+    pl = pl * r + 1.0 / 479001600.0;
+    pl = pl * r + 1.0 / 39916800.0;
+    pl = pl * r + 1.0 / 3628800.0;
+    pl = pl * r + 1.0 / 362880.0;
+    pl = pl * r + 1.0 / 40320.0;
+    pl = pl * r + 1.0 / 5040.0;
+    pl = pl * r + 1.0 / 720.0;
+    pl = pl * r + 1.0 / 120.0;
+    pl = pl * r + 1.0 / 24.0;
+    pl = pl * r + 1.0 / 6.0;
+    pl = pl * r + 0.5;
+    pl = pl * r + 1.0;
+    pl = pl * r + 1.0;
+    const long long k = (long long)kd;
+    union { unsigned long long u; double d; } sc;
+    sc.u = (unsigned long long)(k + 1023) << 52;
+    return pl * sc.d;
+}
+
 // env.py:156-162 comp_pref_vel: unit vector from pos to goal in fp64; zero vector -> (1, 0).
 // Positions are the simulator's fp32, targets are fp64 (Python floats in the reference).
 CA_HD void pref_dir64(float px, float py, double gx, double gy, double* ox, double* oy) {
@@ -84,7 +109,7 @@ CA_HD void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32
     }
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
-enum { RNG_POS = 0, RNG_HEADING = 1, RNG_GOAL = 2, RNG_REGOAL = 3, RNG_RESET = 4 };
+enum { RNG_POS = 0, RNG_HEADING = 1, RNG_GOAL = 2, RNG_REGOAL = 3, RNG_RESET = 4, RNG_ALAN = 5 };
 // two uniforms in [0,1) with 53 random bits each; stream = (seed, global arena, agent, purpose, seq)
 CA_HD void rng2(uint64_t seed, int64_t arena, int agent, int purpose, uint32_t seq, double* u0, double* u1) {
     uint32_t w[4];

@@ -19,9 +19,10 @@ except Exception:  # pragma: no cover
 
 _I32_FIELDS = {_lib.FLD_AGENT_DONE, _lib.FLD_ARRIVE_STEP, _lib.FLD_NB_COUNT, _lib.FLD_NB_IDX,
                _lib.FLD_OBST_COUNT, _lib.FLD_OBST_IDX, _lib.FLD_STEP_COUNT, _lib.FLD_ARENA_DONE,
-               _lib.FLD_EPISODE, _lib.FLD_REGOAL_COUNT}
+               _lib.FLD_EPISODE, _lib.FLD_REGOAL_COUNT, _lib.FLD_ALAN_ACTION}
 _ARENA_FIELDS = {_lib.FLD_STEP_COUNT, _lib.FLD_ARENA_DONE, _lib.FLD_EPISODE}
-_F64_FIELDS = {_lib.FLD_GOAL_X, _lib.FLD_GOAL_Y, _lib.FLD_GOAL2_X, _lib.FLD_GOAL2_Y}
+_F64_FIELDS = {_lib.FLD_GOAL_X, _lib.FLD_GOAL_Y, _lib.FLD_GOAL2_X, _lib.FLD_GOAL2_Y, _lib.FLD_ALAN_WEIGHTS,
+               _lib.FLD_ALAN_TIMES}
 
 
 def _ptr(a):
@@ -66,6 +67,7 @@ class VecCollisionAvoidanceEnv:
             torch.cuda.set_device(self.device)
             self._call("ca_set_stream", self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         self._obs_t = None
+        self.n_actions = 0
         if self.use_torch:
             dev = torch.device("cuda", self.device)
             self._obs_t = torch.zeros((self.A, self.N, _lib.OBS_DIM), dtype=torch.float32, device=dev)
@@ -103,6 +105,8 @@ class VecCollisionAvoidanceEnv:
             return (self.A, self.S, self.N), dt
         if field == _lib.FLD_OBS:
             return (self.A, self.N, _lib.OBS_DIM), dt
+        if field in (_lib.FLD_ALAN_WEIGHTS, _lib.FLD_ALAN_TIMES):
+            return (self.A, self.N, self.n_actions), dt
         return (self.A, self.N), dt
 
     def get(self, field):
@@ -202,10 +206,12 @@ class VecCollisionAvoidanceEnv:
         return (self.get(_lib.FLD_OBS) if with_obs else None), self.get(_lib.FLD_REWARD), \
             self.get(_lib.FLD_ARENA_DONE), {}
 
-    def orca_step(self, with_obs=False, stats=False, no_done=False, autoreset=False):
-        """reference orca_step (env.py:447-458 with no_done=True; ALAN_true.py:631-636 + done test)."""
+    def orca_step(self, with_obs=False, stats=False, no_done=False, autoreset=False, freeze=False):
+        """reference orca_step (env.py:447-458 with no_done=True; ALAN_true.py:631-636 + done test).
+        freeze: arenas whose episode is over are no longer advanced."""
         flags = (_lib.F_OBS if with_obs else 0) | (_lib.F_STATS if stats else 0) | \
-                (_lib.F_NODONE if no_done else 0) | (_lib.F_AUTORESET if autoreset else 0)
+                (_lib.F_NODONE if no_done else 0) | (_lib.F_AUTORESET if autoreset else 0) | \
+                (_lib.F_FREEZE if freeze else 0)
         self._call("ca_orca_step", self.h, flags)
         return self._obs_out() if with_obs else None
 
@@ -214,10 +220,40 @@ class VecCollisionAvoidanceEnv:
         self._call("ca_observe", self.h)
         return self._obs_out()
 
-    def rollout(self, steps, with_obs=False, stats=False, autoreset=False):
+    def rollout(self, steps, with_obs=False, stats=False, autoreset=False, freeze=False):
         flags = (_lib.F_OBS if with_obs else 0) | (_lib.F_STATS if stats else 0) | \
-                (_lib.F_AUTORESET if autoreset else 0)
+                (_lib.F_AUTORESET if autoreset else 0) | (_lib.F_FREEZE if freeze else 0)
         self._call("ca_rollout", self.h, int(steps), flags)
+
+    # ---- ALAN online learning (ALAN_true.py:569-628) -----------------------------------------------
+    def alan_configure(self, actions, temp=0.2, timewindow=2.0, time_step=1 / 60.):
+        """Bandit state of the reference's constructor (ALAN_true.py:31-38, 47-49, 73-76): `actions`
+        [n, 2] vectors, weights and times zeroed."""
+        a = np.ascontiguousarray(np.asarray(actions, np.float64).reshape(-1, 2))
+        self._call("ca_alan_configure", self.h, _ptr(a), a.shape[0], float(temp), float(timewindow), float(time_step))
+        self.n_actions = a.shape[0]
+
+    def alan_step(self, u=None, with_obs=False, stats=False, freeze=False):
+        """reference online_step (ALAN_true.py:569-628) + step counter + goal test (ALAN:118-121).
+        u [A,N] float64: the uniforms behind np.random.choice, one per agent (numpy or device tensor);
+        None: the handle's counter-based RNG."""
+        flags = (_lib.F_OBS if with_obs else 0) | (_lib.F_STATS if stats else 0) | (_lib.F_FREEZE if freeze else 0)
+        if u is None:
+            self._call("ca_alan_step", self.h, None, 0, flags)
+        elif torch is not None and isinstance(u, torch.Tensor):
+            ud = u.to(dtype=torch.float64).contiguous()
+            self._call("ca_alan_step", self.h, C.c_void_p(ud.data_ptr()), 1, flags)
+            self.sync()
+        else:
+            uh = np.ascontiguousarray(np.asarray(u, np.float64).reshape(self.A, self.N))
+            self._call("ca_alan_step", self.h, _ptr(uh), 0, flags)
+        return self._obs_out() if with_obs else None
+
+    def alan_rollout(self, steps, stats=False, freeze=True):
+        """run_sim(mode=1) (ALAN_true.py:106-123) for every arena at once: each arena stops at the end of
+        its own episode (freeze) or after `steps` steps."""
+        flags = (_lib.F_STATS if stats else 0) | (_lib.F_FREEZE if freeze else 0)
+        self._call("ca_alan_rollout", self.h, int(steps), flags)
 
     def state(self):
         names = dict(pos_x=_lib.FLD_POS_X, pos_y=_lib.FLD_POS_Y, vel_x=_lib.FLD_VEL_X, vel_y=_lib.FLD_VEL_Y,

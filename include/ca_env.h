@@ -52,6 +52,10 @@ extern "C" {
 #define CA_F_STATS 2u     /* count collisions (build-defined)                   */
 #define CA_F_AUTORESET 4u /* arenas that finished are reset (env.py:461-488) inside the call   */
 #define CA_F_NODONE 8u    /* ca_orca_step only: no done test, no step counter (env.py:447-450) */
+#define CA_F_FREEZE 16u   /* an arena whose arena_done flag is set is not advanced any more: the
+                             `break` of the reference's episode loops (ALAN:121-123), per arena,
+                             without a host round trip.  ca_reset clears the flag.                */
+#define CA_ALAN_MAX_ACTIONS 32
 
 /* scenarios for ca_init_scenario */
 #define CA_SCN_CROWD 0   /* ALAN:270-294 random start / random goal                            */
@@ -80,6 +84,9 @@ enum ca_field {
     CA_FLD_ARENA_DONE,   /* i32 [A]                                               */
     CA_FLD_EPISODE,      /* i32 [A]                                               */
     CA_FLD_REGOAL_COUNT, /* i32 [A,N]                                             */
+    CA_FLD_ALAN_WEIGHTS, /* f64 [A,N,n_actions] ALAN:75 self.weights (after ca_alan_configure)     */
+    CA_FLD_ALAN_TIMES,   /* f64 [A,N,n_actions] ALAN:76 self.times                                 */
+    CA_FLD_ALAN_ACTION,  /* i32 [A,N] the action executed by the last ca_alan_step (read-only)     */
     CA_FLD__COUNT
 };
 
@@ -159,8 +166,30 @@ int ca_step_host(ca_env* env, const float* actions_host, uint32_t flags);
 int ca_orca_step(ca_env* env, uint32_t flags);
 /* Replaces _get_obs() alone (env.py:231-277): recompute the observation of the current state. */
 int ca_observe(ca_env* env);
-/* `steps` consecutive ca_orca_step calls without returning to the host. */
+/* `steps` consecutive ca_orca_step calls without returning to the host (with CA_F_FREEZE: every
+ * arena runs to the end of its own episode, at most `steps` steps). */
 int ca_rollout(ca_env* env, int32_t steps, uint32_t flags);
+
+/* ALAN online learning (ALAN_true.py:569-628 online_step + the counter / goal test of run_sim,
+ * ALAN:118-121), for every agent of every arena on the device.
+ * ca_alan_configure replaces the constructor's bandit state (ALAN:31-38, 47-49, 73-76):
+ *   actions_xy : HOST array [n_actions, 2] of action vectors (ALAN:31-38); an action rotates the goal
+ *                direction by atan2(y, x) (ALAN:592-595)
+ *   temp       : softmax temperature (ALAN:49 online_temp = 0.2)
+ *   timewindow : seconds after which an action's weight is forgotten (ALAN:48 = 2)
+ *   time_step  : the fp64 time step the reference adds to `times` (ALAN:15 = 1/60.)
+ * Weights and times start at zero.
+ * ca_alan_step: softmax draw -> preferred velocity -> ORCA step -> reward -> bandit update -> step
+ * counter -> goal test.  u: device or host array [A,N] f64 of uniforms in [0,1) that drive the draws (one per
+ * agent, consumed like numpy's choice: first action whose normalised cdf exceeds u), or NULL to use
+ * the handle's counter-based RNG keyed by (seed, global arena, agent, step).  Flags: CA_F_OBS,
+ * CA_F_STATS, CA_F_FREEZE. */
+int ca_alan_configure(ca_env* env, const double* actions_xy, int32_t n_actions, double temp, double timewindow,
+                      double time_step);
+int ca_alan_step(ca_env* env, const double* u, int32_t u_is_device, uint32_t flags);
+/* `steps` consecutive ca_alan_step(env, NULL, 0, flags) calls without returning to the host: with
+ * CA_F_FREEZE this is run_sim(mode=1) (ALAN:106-123) for every arena at once. */
+int ca_alan_rollout(ca_env* env, int32_t steps, uint32_t flags);
 
 /* Blocks until the stream is idle, then returns the counters accumulated so far. */
 int ca_get_stats(ca_env* env, ca_stats* out);
@@ -173,6 +202,7 @@ int ca_sync(ca_env* env);
  * op 2: sincos64(x)         in f64[n]        out f64[2n]
  * op 3: pref_dir64          in f32[4n]       out f64[2n]
  * op 4: philox4x32 uniform  in u32[4n]       out f64[2n]   (key = seed of the handle)
+ * op 5: exp64(x)            in f64[n]        out f64[n]
  * Host pointers. */
 int ca_debug_math(ca_env* env, int32_t op, const void* in, void* out, int32_t n);
 

@@ -844,6 +844,7 @@ void arena_reward(Env& e, int a) { /* env.py:389-400 */
 /* one arena through one env step.  actions != null: env.py:367-416 `step`;
  * actions == null: env.py:447-450 / ALAN:631-636 `orca_step` (+ the caller's done test) */
 void arena_step(Env& e, int a, const float* actions, uint32_t flags, int prec) {
+    if ((flags & ORC_F_FREEZE) && e.arena_done[a]) return;
     Arena& ar = e.arenas[a];
     const int N = e.N();
     const orc_config& c = e.cfg;
@@ -889,6 +890,7 @@ void arena_step(Env& e, int a, const float* actions, uint32_t flags, int prec) {
 /* ALAN_true.py:569-628 online_step for one arena (+ the step counter / done test of run_sim,
  * ALAN_true.py:119-121).  u: this arena's uniforms [N] or null. */
 void arena_alan_step(Env& e, int a, const double* u, uint32_t flags, int prec) {
+    if ((flags & ORC_F_FREEZE) && e.arena_done[a]) return;
     Arena& ar = e.arenas[a];
     const int N = e.N(), nA = e.n_actions;
     const orc_config& c = e.cfg;
@@ -1251,7 +1253,7 @@ int orc_env_rollout(void* env, int32_t steps, uint32_t flags, int32_t n_threads)
 int orc_env_alan_configure(void* env, const double* actions_xy, int32_t n_actions, double temp, double timewindow,
                            double time_step) {
     Env* e = (Env*)env;
-    if (n_actions < 1 || n_actions > 64 || !actions_xy) return -1;
+    if (n_actions < 1 || n_actions > 32 || !actions_xy) return -1;
     e->n_actions = n_actions;
     e->alan_temp = temp;
     e->alan_window = timewindow;

@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "libca_oracle.so")
 
 OBS_DIM = 64
 DONE_XLESS, DONE_GOAL, DONE_REGOAL = 0, 1, 2
-F_OBS, F_STATS, F_AUTORESET, F_NODONE = 1, 2, 4, 8
+F_OBS, F_STATS, F_AUTORESET, F_NODONE, F_FREEZE = 1, 2, 4, 8, 16
 PREC_F32, PREC_F64 = 0, 1
 SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN_DEADLOCK = range(7)
 

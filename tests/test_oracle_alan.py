@@ -78,3 +78,31 @@ def test_softmax_draw_pieces():
     px2, act2 = run(1, 2)
     np.testing.assert_array_equal(px[2], px2[0]); np.testing.assert_array_equal(act[2], act2[0])
     assert len(np.unique(act)) > 1
+
+
+def test_freeze_is_the_break_of_run_sim():
+    """ORC_F_FREEZE: an arena stepped inside a batch until everything is done ends in the state it has when
+    it is run alone and the loop breaks at its own end (ALAN_true.py:118-123)."""
+    n = 6
+    p = scenarios.alan_params(n, "crowd")
+    p["max_step"] = 900
+
+    def make(A, off):
+        e = o.OracleEnv(o.make_config(n_arenas=A, n_agents=n, seed=11, arena_offset=off, **p))
+        e.set_obstacles(scenarios.obstacles("crowd", n)); e.init_scenario(o.SCN_CROWD)
+        e.alan_configure([(1, 0), (0, 1), (0, -1)])
+        return e
+    batch = make(4, 0)
+    for _ in range(900):
+        batch.alan_step(flags=o.F_FREEZE | o.F_STATS)
+    assert batch.get(o.FLD_ARENA_DONE).all()
+    total = 0
+    for a in range(4):
+        single = make(1, a)
+        while not single.get(o.FLD_ARENA_DONE)[0]:
+            single.alan_step(flags=o.F_STATS)
+        for f in (o.FLD_POS_X, o.FLD_VEL_Y, o.FLD_ALAN_WEIGHTS, o.FLD_ALAN_TIMES, o.FLD_ARRIVE_STEP, o.FLD_STEP_COUNT):
+            np.testing.assert_array_equal(batch.get(f)[a], single.get(f)[0])
+        total += single.stats()["agent_steps"]
+    assert batch.stats()["agent_steps"] == total
+    assert len(set(batch.get(o.FLD_STEP_COUNT).tolist())) > 1
