@@ -17,12 +17,12 @@ SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN
 (FLD_POS_X, FLD_POS_Y, FLD_VEL_X, FLD_VEL_Y, FLD_PREF_X, FLD_PREF_Y, FLD_GOAL_X, FLD_GOAL_Y,
  FLD_GOAL2_X, FLD_GOAL2_Y, FLD_REWARD, FLD_AGENT_DONE, FLD_ARRIVE_STEP, FLD_NB_COUNT, FLD_NB_IDX,
  FLD_OBST_COUNT, FLD_OBST_IDX, FLD_OBS, FLD_STEP_COUNT, FLD_ARENA_DONE, FLD_EPISODE,
- FLD_REGOAL_COUNT, FLD_ALAN_WEIGHTS, FLD_ALAN_TIMES, FLD_ALAN_ACTION) = range(25)
+ FLD_REGOAL_COUNT, FLD_ALAN_WEIGHTS, FLD_ALAN_TIMES, FLD_ALAN_ACTION, FLD_ARENA_STATS) = range(26)
 
 EXPORTS = ("ca_create", "ca_destroy", "ca_last_error", "ca_set_stream", "ca_set_obstacles", "ca_init_scenario", "ca_set",
            "ca_get", "ca_field_ptr", "ca_bind_obs", "ca_reset", "ca_step", "ca_step_host", "ca_orca_step", "ca_observe", "ca_rollout",
            "ca_get_stats", "ca_reset_stats", "ca_sync", "ca_debug_math", "ca_profile", "ca_profile_read", "ca_launch_info",
-           "ca_alan_configure", "ca_alan_step", "ca_alan_rollout")
+           "ca_alan_configure", "ca_alan_step", "ca_alan_rollout", "ca_reset_masked")
 
 
 class Config(C.Structure):
@@ -80,6 +80,7 @@ def load():
     L.ca_field_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz)]
     L.ca_bind_obs.argtypes = [vp, vp, sz]
     L.ca_reset.argtypes = [vp, vp, vp, i32, u32]
+    L.ca_reset_masked.argtypes = [vp, vp, i32, u32]
     L.ca_step.argtypes = [vp, vp, u32]
     L.ca_step_host.argtypes = [vp, vp, u32]
     L.ca_orca_step.argtypes = [vp, u32]

@@ -40,6 +40,7 @@ struct ca_env {
     // [A*N][4] fp64 directions of the step in flight
     double *alan_w = nullptr, *alan_t = nullptr, *alan_dirs = nullptr, *alan_u = nullptr;
     int* alan_action = nullptr;
+    int* mask_buf = nullptr;  // staging for ca_reset_masked's host mask
     int n_actions = 0;
     double act_c[CA_ALAN_MAX_ACTIONS], act_s[CA_ALAN_MAX_ACTIONS];
     double alan_temp = 0.2, alan_window = 2.0, alan_dt = 1.0 / 60.0;
@@ -133,6 +134,7 @@ static FieldInfo field_info(ca_env* e, int f) {
         case CA_FLD_ALAN_WEIGHTS: return {e->alan_w, an * 8 * (size_t)e->n_actions, true};
         case CA_FLD_ALAN_TIMES: return {e->alan_t, an * 8 * (size_t)e->n_actions, true};
         case CA_FLD_ALAN_ACTION: return {e->alan_action, an * 4, false};
+        case CA_FLD_ARENA_STATS: return {e->arena_stats, A * ST_STRIDE * 8, false};
         default: return {nullptr, 0, false};
     }
 }
@@ -169,7 +171,7 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.nb_count = e->nb_count; a.nb_idx = e->nb_idx; a.obst_count = e->obst_count; a.obst_idx = e->obst_idx;
     a.step_count = e->step_count; a.arena_done = e->arena_done; a.episode = e->episode;
     a.arena_stats = e->arena_stats; a.obst = e->d_obst; a.actions = actions;
-    a.reset_px = nullptr; a.reset_py = nullptr; a.dbg = e->dbg;
+    a.reset_px = nullptr; a.reset_py = nullptr; a.reset_mask = nullptr; a.dbg = e->dbg;
     a.reward_scale = c.reward_scale; a.seed = c.seed; a.arena_offset = c.arena_offset;
     a.n_obst = (int)e->h_obst.size(); a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
     a.K = e->K; a.S = e->S; a.flags = flags; a.a0 = 0; a.a1 = c.n_arenas;
@@ -373,7 +375,7 @@ int ca_destroy(ca_env* e) {
                     e->agent_done, e->arrive_step,
                     e->regoal_count, e->nb_count, e->nb_idx, e->obst_count, e->obst_idx, e->step_count,
                     e->arena_done, e->episode, e->arena_stats, e->d_obst, e->dbg, e->dbg_obs,
-                    e->alan_w, e->alan_t, e->alan_dirs, e->alan_u, e->alan_action};
+                    e->alan_w, e->alan_t, e->alan_dirs, e->alan_u, e->alan_action, e->mask_buf};
     for (void* b : bufs) if (b) hipFree(b);
     if (e->obs && !e->obs_external) hipFree(e->obs);
     for (const ca_env::Span& sp : e->spans) { hipEventDestroy(sp.t0); hipEventDestroy(sp.t1); }
@@ -610,6 +612,31 @@ int ca_reset(ca_env* e, const float* pos_x, const float* pos_y, int32_t pos_is_d
     }
     HIPCHK(e, hipGetLastError());
     e->orient_valid = true;
+    if (flags & CA_F_OBS) HIPCHK(e, launch_obs(e));
+    return CA_OK;
+}
+
+int ca_reset_masked(ca_env* e, const int32_t* mask, int32_t mask_is_device, uint32_t flags) {
+    if (!e || !mask) return fail(e, CA_EINVAL, "ca_reset_masked: null argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    const int A = e->cfg.n_arenas;
+    if (!mask_is_device) {
+        if (!e->mask_buf) HIPCHK(e, dalloc(&e->mask_buf, (size_t)A));
+        HIPCHK(e, hipMemcpyAsync(e->mask_buf, mask, (size_t)A * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        mask = e->mask_buf;
+    }
+    StepArgs a;
+    fill_args(e, a, nullptr, flags);
+    a.reset_mask = mask;
+    const unsigned an = (unsigned)AN(e);
+    {
+    ProfScope ps(e, KIND_RESET);
+    hipLaunchKernelGGL(reset_kernel, dim3((an + 255) / 256), dim3(256), 0, e->stream, a);
+    HIPCHK(e, hipGetLastError());
+    hipLaunchKernelGGL(reset_arena_kernel, dim3((A + 255) / 256), dim3(256), 0, e->stream, a);
+    }
+    HIPCHK(e, hipGetLastError());
     if (flags & CA_F_OBS) HIPCHK(e, launch_obs(e));
     return CA_OK;
 }

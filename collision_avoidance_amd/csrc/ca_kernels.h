@@ -47,6 +47,7 @@ struct StepArgs {
     const float* actions;  // null: orca_step
     const float* reset_px; // explicit reset positions (reset kernel only)
     const float* reset_py;
+    const int* reset_mask; // [A] reset only the arenas with a non-zero entry (reset kernels only; null = all)
     unsigned long long* dbg;  // CA_STAMPS diagnostic build only: [waves][16] phase cycle counts
     double reward_scale;
     uint64_t seed;
@@ -60,7 +61,7 @@ struct StepArgs {
     float spawn_x0, spawn_x1, spawn_y0, spawn_y1, goal_x0, goal_x1, goal_y0, goal_y1;
 };
 
-enum { ST_EPISODES = 0, ST_COLL = 1, ST_OBST_COLL = 2, ST_GOALS = 3, ST_OVERFLOW = 4, ST_SUMREW = 5, ST_FROZEN = 6, ST_STRIDE = 8 };
+enum { ST_EPISODES = 0, ST_COLL = 1, ST_OBST_COLL = 2, ST_GOALS = 3, ST_OVERFLOW = 4, ST_SUMREW = 5, ST_FROZEN = 6, ST_LASTEP = 7, ST_STRIDE = 8 };
 
 // CA_F_FREEZE: arenas whose arena_done flag is set are left exactly as they are
 __device__ __forceinline__ bool arena_frozen(const StepArgs& p, int a) {
@@ -922,7 +923,10 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
             if (red[1]) st[ST_COLL] += (unsigned)red[1];
             if (red[2]) st[ST_OBST_COLL] += (unsigned)red[2];
             if (red[3]) st[ST_GOALS] += (unsigned)red[3];
-            if (all_done) st[ST_EPISODES] += 1;
+            if (all_done) {  // + what a caller that auto-resets wants to know about the episode that ended
+                st[ST_EPISODES] += 1;
+                st[ST_LASTEP] = ((unsigned long long)(unsigned)steps << 32) | (unsigned)(N - red[0]);
+            }
             p.arena_done[a] = all_done ? 1 : 0;
             p.step_count[a] = do_reset ? 0 : steps;
             if (do_reset) p.episode[a] = epi + 1;
@@ -939,6 +943,7 @@ __global__ void reset_kernel(const StepArgs p) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= p.A * p.N) return;
     const int a = q / p.N, i = q - a * p.N;
+    if (p.reset_mask && p.reset_mask[a] == 0) return;
     V2 pos;
     if (p.reset_px) {
         pos = mk(p.reset_px[q], p.reset_py[q]);
@@ -966,6 +971,7 @@ __global__ void orient_kernel(const StepArgs p) {
 __global__ void reset_arena_kernel(const StepArgs p) {  // after reset_kernel: per-arena counters
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= p.A) return;
+    if (p.reset_mask && p.reset_mask[a] == 0) return;
     p.step_count[a] = 0;
     p.arena_done[a] = 0;
     p.episode[a] += 1;

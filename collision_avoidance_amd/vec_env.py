@@ -96,6 +96,8 @@ class VecCollisionAvoidanceEnv:
             pass
 
     def _shape_dtype(self, field):
+        if field == _lib.FLD_ARENA_STATS:
+            return (self.A, 8), np.uint64
         dt = np.int32 if field in _I32_FIELDS else (np.float64 if field in _F64_FIELDS else np.float32)
         if field in _ARENA_FIELDS:
             return (self.A,), dt
@@ -185,6 +187,26 @@ class VecCollisionAvoidanceEnv:
             py = np.ascontiguousarray(np.asarray(pos_y, np.float32).reshape(self.A, self.N))
             self._call("ca_reset", self.h, _ptr(px), _ptr(py), 0, flags)
         return self._obs_out() if with_obs else None
+
+    def reset_masked(self, mask, with_obs=True):
+        """reset() for the arenas with mask[a] != 0 only (numpy or device int32 tensor [A])."""
+        flags = _lib.F_OBS if with_obs else 0
+        if torch is not None and isinstance(mask, torch.Tensor):
+            m = mask.to(dtype=torch.int32).contiguous()
+            self._call("ca_reset_masked", self.h, C.c_void_p(m.data_ptr()), 1, flags)
+            self.sync()
+        else:
+            m = np.ascontiguousarray(np.asarray(mask, np.int32).reshape(self.A))
+            self._call("ca_reset_masked", self.h, _ptr(m), 0, flags)
+        return self._obs_out() if with_obs else None
+
+    def arena_stats(self):
+        """Per-arena counters as a dict of [A] arrays (synchronises)."""
+        r = self.get(_lib.FLD_ARENA_STATS)
+        return dict(episodes=r[:, 0], collisions=r[:, 1], obst_collisions=r[:, 2], goals_reached=r[:, 3],
+                    obst_overflow=r[:, 4], sum_reward=r[:, 5].copy().view(np.float64), frozen_steps=r[:, 6],
+                    last_episode_steps=(r[:, 7] >> np.uint64(32)).astype(np.int64),
+                    last_episode_arrived=(r[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.int64))
 
     def step(self, actions, with_obs=True, stats=False, autoreset=False):
         """reference step(action) (env.py:367-416) for every arena.

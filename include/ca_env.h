@@ -87,6 +87,9 @@ enum ca_field {
     CA_FLD_ALAN_WEIGHTS, /* f64 [A,N,n_actions] ALAN:75 self.weights (after ca_alan_configure)     */
     CA_FLD_ALAN_TIMES,   /* f64 [A,N,n_actions] ALAN:76 self.times                                 */
     CA_FLD_ALAN_ACTION,  /* i32 [A,N] the action executed by the last ca_alan_step (read-only)     */
+    CA_FLD_ARENA_STATS,  /* u64 [A,8] per-arena counters (read-only): episodes, collisions, obst_collisions,
+                            goals_reached, obst_overflow, sum_reward (f64 bits), steps sat out under
+                            CA_F_FREEZE, last finished episode (length << 32 | agents that arrived)   */
     CA_FLD__COUNT
 };
 
@@ -157,6 +160,10 @@ int ca_bind_obs(ca_env* env, void* dev_ptr, size_t bytes);
 /* Replaces reset() (env.py:461-488).  pos_x/pos_y: device or host arrays [A,N] with the new
  * positions, or NULL to draw them from the spawn box with the counter-based RNG. */
 int ca_reset(ca_env* env, const float* pos_x, const float* pos_y, int32_t pos_is_device, uint32_t flags);
+
+/* The same for the arenas with mask[a] != 0 only, positions drawn from the spawn box: what a vector-env
+ * front end needs for reset_at(index) / try_reset(env_id).  mask: i32 [A], device or host. */
+int ca_reset_masked(ca_env* env, const int32_t* mask, int32_t mask_is_device, uint32_t flags);
 
 /* Replaces step(action) (env.py:367-416).  actions: DEVICE array [A,N] f32 of heading offsets. */
 int ca_step(ca_env* env, const float* actions, uint32_t flags);

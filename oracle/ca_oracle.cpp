@@ -656,6 +656,7 @@ struct Env {
     std::vector<double> rl64;   /* scratch: action-rotated preferred direction, [A*N*2] */
     std::vector<double> pf64;   /* scratch: goal direction before the step, [A*N*2]     */
     std::vector<orc_stats> st;  /* per arena, summed on read                             */
+    std::vector<uint64_t> frozen_steps, last_episode; /* [A]: steps sat out under FREEZE; (length << 32 | agents arrived) of the last finished episode */
     /* ALAN online learning state (ALAN_true.py:30-49, 141-142) */
     int n_actions = 0;
     double alan_temp = 0.2, alan_window = 2.0, alan_dt = 1.0 / 60.0;  /* Python floats of the reference */
@@ -822,6 +823,13 @@ void arena_reset(Env& e, int a, const float* px, const float* py) {
     e.episode[a] += 1;
 }
 
+/* bookkeeping for callers that auto-reset: length of the episode that just ended and how many agents arrived */
+void note_episode_end(Env& e, int a) {
+    uint64_t arrived = 0;
+    for (int i = 0; i < e.N(); ++i) arrived += e.agent_done[(size_t)a * e.N() + i] != 0;
+    e.last_episode[a] = ((uint64_t)(uint32_t)e.step_count[a] << 32) | arrived;
+}
+
 template <class T>
 void arena_reward(Env& e, int a) { /* env.py:389-400 */
     Arena& ar = e.arenas[a];
@@ -844,7 +852,7 @@ void arena_reward(Env& e, int a) { /* env.py:389-400 */
 /* one arena through one env step.  actions != null: env.py:367-416 `step`;
  * actions == null: env.py:447-450 / ALAN:631-636 `orca_step` (+ the caller's done test) */
 void arena_step(Env& e, int a, const float* actions, uint32_t flags, int prec) {
-    if ((flags & ORC_F_FREEZE) && e.arena_done[a]) return;
+    if ((flags & ORC_F_FREEZE) && e.arena_done[a]) { e.frozen_steps[a] += 1; return; }
     Arena& ar = e.arenas[a];
     const int N = e.N();
     const orc_config& c = e.cfg;
@@ -882,6 +890,7 @@ void arena_step(Env& e, int a, const float* actions, uint32_t flags, int prec) {
     e.arena_done[a] = all_done;
     if (all_done) {
         e.st[a].episodes += 1;
+        note_episode_end(e, a);
         if (flags & ORC_F_AUTORESET) arena_reset(e, a, nullptr, nullptr);
     }
     if (flags & ORC_F_OBS) arena_obs(e, a, prec);
@@ -890,7 +899,7 @@ void arena_step(Env& e, int a, const float* actions, uint32_t flags, int prec) {
 /* ALAN_true.py:569-628 online_step for one arena (+ the step counter / done test of run_sim,
  * ALAN_true.py:119-121).  u: this arena's uniforms [N] or null. */
 void arena_alan_step(Env& e, int a, const double* u, uint32_t flags, int prec) {
-    if ((flags & ORC_F_FREEZE) && e.arena_done[a]) return;
+    if ((flags & ORC_F_FREEZE) && e.arena_done[a]) { e.frozen_steps[a] += 1; return; }
     Arena& ar = e.arenas[a];
     const int N = e.N(), nA = e.n_actions;
     const orc_config& c = e.cfg;
@@ -941,7 +950,7 @@ void arena_alan_step(Env& e, int a, const double* u, uint32_t flags, int prec) {
     int all_done = arena_done_test(e, a);                   /* ALAN:121 */
     if (c.max_step > 0 && e.step_count[a] >= c.max_step) all_done = 1;
     e.arena_done[a] = all_done;
-    if (all_done) e.st[a].episodes += 1;
+    if (all_done) { e.st[a].episodes += 1; note_episode_end(e, a); }
     if (flags & ORC_F_OBS) arena_obs(e, a, prec);
 }
 
@@ -997,6 +1006,7 @@ void* orc_env_create(const orc_config* cfg) {
     e->step_count.assign(A, 0); e->arena_done.assign(A, 0); e->episode.assign(A, 0);
     e->rl64.assign(A * N * 2, 0); e->pf64.assign(A * N * 2, 0);
     e->st.assign(A, orc_stats{});
+    e->frozen_steps.assign(A, 0); e->last_episode.assign(A, 0);
     env_tables(*e);
     return e;
 }
@@ -1161,6 +1171,18 @@ static int env_access(Env* e, int field, const void* src, void* dst, size_t byte
         case ORC_FLD_ALAN_WEIGHTS: return write ? copy_in(e->alan_w, src, bytes) : copy_out(e->alan_w, dst, bytes);
         case ORC_FLD_ALAN_TIMES: return write ? copy_in(e->alan_t, src, bytes) : copy_out(e->alan_t, dst, bytes);
         case ORC_FLD_ALAN_ACTION: return write ? copy_in(e->alan_action, src, bytes) : copy_out(e->alan_action, dst, bytes);
+        case ORC_FLD_ARENA_STATS: {
+            if (write) return -3;
+            std::vector<uint64_t> rows((size_t)e->A() * 8, 0);
+            for (int a = 0; a < e->A(); ++a) {
+                uint64_t* r = &rows[(size_t)a * 8];
+                r[0] = e->st[a].episodes; r[1] = e->st[a].collisions; r[2] = e->st[a].obst_collisions;
+                r[3] = e->st[a].goals_reached; r[4] = e->st[a].obst_overflow;
+                std::memcpy(&r[5], &e->st[a].sum_reward, 8);
+                r[6] = e->frozen_steps[a]; r[7] = e->last_episode[a];
+            }
+            return copy_out(rows, dst, bytes);
+        }
         case ORC_FLD_NB_COUNT:
         case ORC_FLD_OBST_COUNT: {
             std::vector<int32_t> tmp((size_t)A * N);
@@ -1212,6 +1234,18 @@ int orc_env_reset(void* env, const float* pos_x, const float* pos_y, uint32_t fl
     Env* e = (Env*)env;
     for (int a = 0; a < e->A(); ++a) {
         arena_reset(*e, a, pos_x, pos_y);
+        e->arena_done[a] = 0;
+        if (flags & ORC_F_OBS) arena_obs(*e, a, prec);
+    }
+    return 0;
+}
+
+int orc_env_reset_masked(void* env, const int32_t* mask, uint32_t flags, int32_t prec) {
+    Env* e = (Env*)env;
+    if (!mask) return -1;
+    for (int a = 0; a < e->A(); ++a) {
+        if (!mask[a]) continue;
+        arena_reset(*e, a, nullptr, nullptr);
         e->arena_done[a] = 0;
         if (flags & ORC_F_OBS) arena_obs(*e, a, prec);
     }

@@ -21,7 +21,7 @@ SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN
 (FLD_POS_X, FLD_POS_Y, FLD_VEL_X, FLD_VEL_Y, FLD_PREF_X, FLD_PREF_Y, FLD_GOAL_X, FLD_GOAL_Y,
  FLD_GOAL2_X, FLD_GOAL2_Y, FLD_REWARD, FLD_AGENT_DONE, FLD_ARRIVE_STEP, FLD_NB_COUNT, FLD_NB_IDX,
  FLD_OBST_COUNT, FLD_OBST_IDX, FLD_OBS, FLD_OBS64, FLD_REWARD64, FLD_STEP_COUNT, FLD_ARENA_DONE,
- FLD_EPISODE, FLD_REGOAL_COUNT, FLD_ALAN_WEIGHTS, FLD_ALAN_TIMES, FLD_ALAN_ACTION) = range(27)
+ FLD_EPISODE, FLD_REGOAL_COUNT, FLD_ALAN_WEIGHTS, FLD_ALAN_TIMES, FLD_ALAN_ACTION, FLD_ARENA_STATS) = range(28)
 
 
 class Config(C.Structure):
@@ -74,6 +74,7 @@ def lib():
     L.orc_env_set.argtypes = [vp, i32, vp, sz]
     L.orc_env_get.argtypes = [vp, i32, vp, sz]
     L.orc_env_reset.argtypes = [vp, vp, vp, u32, i32]
+    L.orc_env_reset_masked.argtypes = [vp, vp, u32, i32]
     L.orc_env_step.argtypes = [vp, vp, u32, i32]
     L.orc_env_orca_step.argtypes = [vp, u32, i32]
     L.orc_env_rollout.argtypes = [vp, i32, u32, i32]
@@ -155,6 +156,8 @@ class OracleEnv:
             self.h = None
 
     def _shape_dtype(self, field):
+        if field == FLD_ARENA_STATS:
+            return (self.A, 8), np.uint64
         if field in _ARENA_FIELDS:
             return (self.A,), np.int32
         last, dt = _FIELD_SHAPES.get(field, (None, np.float32))
@@ -204,6 +207,10 @@ class OracleEnv:
             py = np.ascontiguousarray(np.asarray(pos_y, np.float32).reshape(self.A, self.N))
             rc = self.L.orc_env_reset(self.h, _ptr(px), _ptr(py), flags, prec)
         assert rc == 0
+
+    def reset_masked(self, mask, flags=F_OBS, prec=PREC_F32):
+        m = np.ascontiguousarray(np.asarray(mask, np.int32).reshape(self.A))
+        assert self.L.orc_env_reset_masked(self.h, _ptr(m), flags, prec) == 0
 
     def step(self, actions, flags=F_OBS, prec=PREC_F32):
         a = np.ascontiguousarray(np.asarray(actions, np.float32).reshape(self.A, self.N))

@@ -90,3 +90,45 @@ def assert_stats_equal(gpu, orc, what=""):
     for k in ("agent_steps", "episodes", "collisions", "obst_collisions", "goals_reached", "obst_overflow"):
         assert g[k] == s[k], "%s stats.%s gpu=%d oracle=%d" % (what, k, g[k], s[k])
     assert abs(g["sum_reward"] - s["sum_reward"]) <= 1e-9 * max(1.0, abs(s["sum_reward"])), (g, s)
+
+
+class OracleVec(object):
+    """The subset of VecCollisionAvoidanceEnv's interface that the adapters use, backed by the CPU oracle:
+    lets the host-side adapter logic be tested without a GPU and gives the GPU tests their reference."""
+    use_torch = False
+
+    def __init__(self, A, N, scenario, params, seed=0):
+        self.env = make_oracle(A, N, scenario, params, seed=seed)
+        self.A, self.N, self.cfg = A, N, self.env.cfg
+
+    def _fld(self, field):
+        from collision_avoidance_amd import _lib
+        name = [k for k in dir(_lib) if k.startswith("FLD_") and getattr(_lib, k) == field][0]
+        return getattr(o, name)
+
+    def get(self, field):
+        return self.env.get(self._fld(field))
+
+    def reset(self, with_obs=True):
+        self.env.reset(flags=o.F_OBS if with_obs else 0)
+        return self.env.get(o.FLD_OBS) if with_obs else None
+
+    def reset_masked(self, mask, with_obs=True):
+        self.env.reset_masked(mask, flags=o.F_OBS if with_obs else 0)
+        return self.env.get(o.FLD_OBS) if with_obs else None
+
+    def step(self, actions, with_obs=True, stats=False, autoreset=False):
+        flags = (o.F_OBS if with_obs else 0) | (o.F_STATS if stats else 0) | (o.F_AUTORESET if autoreset else 0)
+        self.env.step(actions, flags=flags)
+        return (self.env.get(o.FLD_OBS) if with_obs else None), self.env.get(o.FLD_REWARD), \
+            self.env.get(o.FLD_ARENA_DONE), {}
+
+    def arena_stats(self):
+        r = self.env.get(o.FLD_ARENA_STATS)
+        return dict(episodes=r[:, 0], collisions=r[:, 1], obst_collisions=r[:, 2], goals_reached=r[:, 3],
+                    obst_overflow=r[:, 4], sum_reward=r[:, 5].copy().view(np.float64), frozen_steps=r[:, 6],
+                    last_episode_steps=(r[:, 7] >> np.uint64(32)).astype(np.int64),
+                    last_episode_arrived=(r[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.int64))
+
+    def close(self):
+        pass
