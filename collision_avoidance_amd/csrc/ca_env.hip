@@ -258,6 +258,76 @@ static hipError_t launch_obs(ca_env* e) {
     return hipGetLastError();
 }
 
+// What sim.processObstacles() (env.py:123, ALAN:209) does to the vertex table in the RVO2 library: its
+// obstacle BSP tree picks, per node, the edge whose supporting line balances the remaining edges best
+// (smallest (max(left, right), min(left, right)), first one wins) and cuts every edge that crosses that
+// line; the cut points become new vertices at the end of the table (convex, direction of the edge they
+// sit on) and are what getObstacleVertex / getNextObstacleVertexNo (env.py:307-311) and the neighbour
+// query see afterwards.  The kernels scan edges brute force, so only the cuts are kept, not the tree.
+// Work list instead of recursion; a node's left set is expanded before its right set, which is the
+// order in which the library numbers the new vertices.
+static void split_crossing_edges(std::vector<ObstDev>& tab) {
+    struct Side { int left, right; };
+    auto sides = [&](int split, int edge, float* a, float* b) {
+        const V2 s1 = mk(tab[split].px, tab[split].py), s2 = mk(tab[tab[split].next].px, tab[tab[split].next].py);
+        *a = leftOf(s1, s2, mk(tab[edge].px, tab[edge].py));
+        *b = leftOf(s1, s2, mk(tab[tab[edge].next].px, tab[tab[edge].next].py));
+    };
+    auto worse_or_equal = [](Side x, Side y) {  // (max, min) of x >= (max, min) of y
+        const int xm = x.left > x.right ? x.left : x.right, xn = x.left < x.right ? x.left : x.right;
+        const int ym = y.left > y.right ? y.left : y.right, yn = y.left < y.right ? y.left : y.right;
+        return xm > ym || (xm == ym && xn >= yn);
+    };
+    std::vector<std::vector<int>> work(1);
+    for (int i = 0; i < (int)tab.size(); ++i) work[0].push_back(i);
+    while (!work.empty()) {
+        const std::vector<int> edges = std::move(work.back());
+        work.pop_back();
+        const int n = (int)edges.size();
+        if (n == 0) continue;
+        int pick = 0;
+        Side best = {n, n};
+        for (int i = 0; i < n; ++i) {
+            Side c = {0, 0};
+            for (int j = 0; j < n; ++j) {
+                if (j == i) continue;
+                float a, b;
+                sides(edges[i], edges[j], &a, &b);
+                if (a >= -EPS && b >= -EPS) ++c.left;
+                else if (a <= EPS && b <= EPS) ++c.right;
+                else { ++c.left; ++c.right; }
+                if (worse_or_equal(c, best)) break;
+            }
+            if (!worse_or_equal(c, best)) { best = c; pick = i; }
+        }
+        std::vector<int> lhs, rhs;
+        const int sp = edges[pick];
+        const V2 s1 = mk(tab[sp].px, tab[sp].py), s2 = mk(tab[tab[sp].next].px, tab[tab[sp].next].py);
+        for (int j = 0; j < n; ++j) {
+            if (j == pick) continue;
+            const int e1 = edges[j], e2 = tab[e1].next;
+            float a, b;
+            sides(sp, e1, &a, &b);
+            if (a >= -EPS && b >= -EPS) { lhs.push_back(e1); continue; }
+            if (a <= EPS && b <= EPS) { rhs.push_back(e1); continue; }
+            const V2 p1 = mk(tab[e1].px, tab[e1].py), p2 = mk(tab[e2].px, tab[e2].py);
+            const float t = det(s2 - s1, p1 - s1) / det(s2 - s1, p1 - p2);
+            const V2 cut = p1 + t * (p2 - p1);
+            ObstDev o;
+            memset(&o, 0, sizeof o);
+            o.px = cut.x; o.py = cut.y; o.ux = tab[e1].ux; o.uy = tab[e1].uy;
+            o.prev = e1; o.next = e2; o.convex = 1;
+            const int id = (int)tab.size();
+            tab.push_back(o);
+            tab[e1].next = id; tab[e2].prev = id;
+            if (a > 0.0f) { lhs.push_back(e1); rhs.push_back(id); }
+            else { rhs.push_back(e1); lhs.push_back(id); }
+        }
+        work.push_back(std::move(rhs));  // popped after the whole left subtree
+        work.push_back(std::move(lhs));
+    }
+}
+
 template <class T>
 static hipError_t dalloc(T** p, size_t n) {
     hipError_t r = hipMalloc((void**)p, n * sizeof(T));
@@ -416,14 +486,14 @@ int ca_set_obstacles(ca_env* e, const float* verts_xy, const int32_t* poly_sizes
             o.convex = (n == 2) ? 1 : (leftOf(pp, pt, pn) >= 0.0f ? 1 : 0);
             tab.push_back(o);
         }
-        for (int i = 0; i < n; ++i) {  // denormalise: each edge record also carries its two neighbours
-            ObstDev& o = tab[base + i];
-            const ObstDev& nx = tab[o.next];
-            const ObstDev& pv = tab[o.prev];
-            o.qx = nx.px; o.qy = nx.py; o.qux = nx.ux; o.quy = nx.uy; o.qconvex = nx.convex;
-            o.pux = pv.ux; o.puy = pv.uy;
-        }
         off += n;
+    }
+    split_crossing_edges(tab);  // processObstacles (env.py:123)
+    for (ObstDev& o : tab) {  // denormalise: each edge record also carries its two neighbours
+        const ObstDev& nx = tab[o.next];
+        const ObstDev& pv = tab[o.prev];
+        o.qx = nx.px; o.qy = nx.py; o.qux = nx.ux; o.quy = nx.uy; o.qconvex = nx.convex;
+        o.pux = pv.ux; o.puy = pv.uy;
     }
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -433,6 +503,18 @@ int ca_set_obstacles(ca_env* e, const float* verts_xy, const int32_t* poly_sizes
     if (!tab.empty())
         HIPCHK(e, hipMemcpy(e->d_obst, tab.data(), tab.size() * sizeof(ObstDev), hipMemcpyHostToDevice));
     e->h_obst.swap(tab);
+    return CA_OK;
+}
+
+int ca_get_obstacles(ca_env* e, float* verts_xy, int32_t* next, int32_t* convex, int32_t cap, int32_t* n_out) {
+    if (!e || !n_out) return fail(e, CA_EINVAL, "ca_get_obstacles: null argument");
+    const int n = (int)e->h_obst.size();
+    *n_out = n;
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (verts_xy) { verts_xy[2 * i] = e->h_obst[i].px; verts_xy[2 * i + 1] = e->h_obst[i].py; }
+        if (next) next[i] = e->h_obst[i].next;
+        if (convex) convex[i] = e->h_obst[i].convex;
+    }
     return CA_OK;
 }
 

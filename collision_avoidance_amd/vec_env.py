@@ -136,6 +136,15 @@ class VecCollisionAvoidanceEnv:
         sizes = np.asarray([len(q) for q in polys], np.int32)
         self._call("ca_set_obstacles", self.h, _ptr(verts), _ptr(sizes), len(polys))
 
+    def obstacle_table(self):
+        """The processed vertex table (after the edge cuts of processObstacles): dict(verts [n,2], next [n],
+        convex [n]); edge i = verts[i] -> verts[next[i]], the ids of obstacle_neighbor_lists()."""
+        n = C.c_int32()
+        self._call("ca_get_obstacles", self.h, None, None, None, 0, C.byref(n))
+        verts, nxt, cvx = np.zeros((n.value, 2), np.float32), np.zeros(n.value, np.int32), np.zeros(n.value, np.int32)
+        self._call("ca_get_obstacles", self.h, _ptr(verts), _ptr(nxt), _ptr(cvx), n.value, C.byref(n))
+        return dict(verts=verts, next=nxt, convex=cvx)
+
     def init_scenario(self, scenario):
         sid = scenarios.SCENARIO_IDS[scenario] if isinstance(scenario, str) else int(scenario)
         self._call("ca_init_scenario", self.h, sid)

@@ -142,8 +142,14 @@ const char* ca_last_error(const ca_env* env);
 int ca_set_stream(ca_env* env, void* stream);
 
 /* Replaces sim.addObstacle + sim.processObstacles (env.py:118-123, 143-149): the same polygons
- * for every arena.  verts_xy: host array [sum(poly_sizes), 2]. */
+ * for every arena.  verts_xy: host array [sum(poly_sizes), 2].  Like the RVO2 library's
+ * processObstacles, edges that cross the supporting line of a splitting edge of its obstacle tree are cut
+ * there; the cut points are appended to the vertex table behind the caller's vertices. */
 int ca_set_obstacles(ca_env* env, const float* verts_xy, const int32_t* poly_sizes, int32_t n_poly);
+/* Replaces sim.getObstacleVertex / getNextObstacleVertexNo (env.py:148, 208, 307-311): the processed
+ * vertex table.  Edge i runs from vertex i to vertex next[i]; these are the ids in CA_FLD_OBST_IDX.
+ * Host arrays of capacity `cap` (each may be NULL); *n_out = number of vertices. */
+int ca_get_obstacles(ca_env* env, float* verts_xy, int32_t* next, int32_t* convex, int32_t cap, int32_t* n_out);
 
 /* Replaces _init_world's agent loop (env.py:86-97) / ALAN's scenario generators (ALAN:270-330). */
 int ca_init_scenario(ca_env* env, int32_t scenario);

@@ -95,6 +95,63 @@ int add_polygon(std::vector<ObstVertex>& tab, const float* xy, int n) {
     return base;
 }
 
+/* processObstacles (env.py:123, ALAN:209): upstream RVO2 builds a BSP tree over the obstacle edges
+ * (KdTree::buildObstacleTreeRecursive, RVO2 Library v2.0.x).  The tree itself is not needed by a
+ * brute-force edge scan, but building it SPLITS every edge that crosses the supporting line of the
+ * edge chosen at a node, and the new vertices are appended to the simulator's vertex table, where
+ * getObstacleVertex / getNextObstacleVertexNo (env.py:307-311) and the neighbour query see them.
+ * This restates the published recursion and keeps only that side effect.  At a node the splitting edge
+ * is the one minimising (max(left, right), min(left, right)) lexicographically, first minimum wins;
+ * the left subtree is built before the right one, which fixes the numbering of the new vertices. */
+void split_obstacles(std::vector<ObstVertex>& tab, const std::vector<int>& obs) {
+    typedef std::pair<size_t, size_t> SS;
+    const size_t n = obs.size();
+    if (n == 0) return;
+    size_t best = 0, minLeft = n, minRight = n;
+    for (size_t i = 0; i < n; ++i) {
+        size_t l = 0, r = 0;
+        const V2 i1 = tab[obs[i]].p, i2 = tab[tab[obs[i]].next].p;
+        for (size_t j = 0; j < n; ++j) {
+            if (i == j) continue;
+            const float a = leftOf(i1, i2, tab[obs[j]].p), b = leftOf(i1, i2, tab[tab[obs[j]].next].p);
+            if (a >= -EPS && b >= -EPS) ++l;
+            else if (a <= EPS && b <= EPS) ++r;
+            else { ++l; ++r; }
+            if (SS(std::max(l, r), std::min(l, r)) >= SS(std::max(minLeft, minRight), std::min(minLeft, minRight))) break;
+        }
+        if (SS(std::max(l, r), std::min(l, r)) < SS(std::max(minLeft, minRight), std::min(minLeft, minRight))) {
+            minLeft = l; minRight = r; best = i;
+        }
+    }
+    std::vector<int> left, right;
+    const V2 i1 = tab[obs[best]].p, i2 = tab[tab[obs[best]].next].p;
+    for (size_t j = 0; j < n; ++j) {
+        if (j == best) continue;
+        const int j1 = obs[j], j2 = tab[j1].next;
+        const float a = leftOf(i1, i2, tab[j1].p), b = leftOf(i1, i2, tab[j2].p);
+        if (a >= -EPS && b >= -EPS) left.push_back(j1);
+        else if (a <= EPS && b <= EPS) right.push_back(j1);
+        else { /* the edge j1 -> j2 crosses the line: cut it there */
+            const float t = det(i2 - i1, tab[j1].p - i1) / det(i2 - i1, tab[j1].p - tab[j2].p);
+            ObstVertex v;
+            v.p = tab[j1].p + t * (tab[j2].p - tab[j1].p);
+            v.prev = j1; v.next = j2; v.convex = true; v.unitDir = tab[j1].unitDir;
+            const int id = (int)tab.size();
+            tab.push_back(v);
+            tab[j1].next = id; tab[j2].prev = id;
+            if (a > 0.0f) { left.push_back(j1); right.push_back(id); }
+            else { right.push_back(j1); left.push_back(id); }
+        }
+    }
+    split_obstacles(tab, left);
+    split_obstacles(tab, right);
+}
+void process_obstacles(std::vector<ObstVertex>& tab) {
+    std::vector<int> all(tab.size());
+    for (size_t i = 0; i < all.size(); ++i) all[i] = (int)i;
+    split_obstacles(tab, all);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* one arena                                                                                   */
 /* ------------------------------------------------------------------------------------------ */
@@ -1021,6 +1078,7 @@ int orc_env_set_obstacles(void* env, const float* verts_xy, const int32_t* poly_
         if (add_polygon(e->obst, verts_xy + 2 * off, poly_sizes[p]) < 0) return -1;
         off += poly_sizes[p];
     }
+    process_obstacles(e->obst); /* env.py:123 */
     return 0;
 }
 
@@ -1349,7 +1407,7 @@ int orc_sim_add_agent(void* sim, float x, float y, float neighbor_dist, int32_t 
     return i;
 }
 int orc_sim_add_obstacle(void* sim, const float* xy, int32_t n) { return add_polygon(((Sim*)sim)->obst, xy, n); }
-void orc_sim_process_obstacles(void*) {} /* brute-force edge scan needs no tree */
+void orc_sim_process_obstacles(void* sim) { process_obstacles(((Sim*)sim)->obst); }
 void orc_sim_do_step(void* sim) {
     Sim* s = (Sim*)sim;
     do_step(s->ar, s->obst, s->timeStep, std::numeric_limits<int>::max(), nullptr);

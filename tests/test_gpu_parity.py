@@ -324,3 +324,17 @@ def test_full_size_properties():
     assert ob.shape == (A, N, 64) and np.isfinite(ob).all() and np.abs(ob[..., :2]).max() <= 5.0 + 1e-4
     assert np.all(rew <= 1.0 + 1e-5)
     env.close()
+
+
+def test_processed_obstacle_table_equals_oracle():
+    """ca_set_obstacles cuts edges like processObstacles; the vertex table (ids, links, coordinates) is the
+    oracle's, so neighbour ids mean the same thing on both sides."""
+    for scen, n in (("doorway", 10), ("congested", 12), ("blocks", 8), ("deadlock", 10), ("crowd", 16)):
+        p = H.scenario_params(scen, n)
+        g = H.make_gpu(1, n, scen, p)
+        e = H.make_oracle(1, n, scen, p)
+        tg, te = g.obstacle_table(), e.obstacle_table(cap=512)
+        assert len(tg["next"]) == len(te["next"]) >= sum(len(q) for q in scenarios.obstacles(scen, n))
+        np.testing.assert_array_equal(tg["verts"][:, 0], te["px"]); np.testing.assert_array_equal(tg["verts"][:, 1], te["py"])
+        np.testing.assert_array_equal(tg["next"], te["next"]); np.testing.assert_array_equal(tg["convex"], te["convex"])
+        g.close()
