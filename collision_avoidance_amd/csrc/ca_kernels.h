@@ -482,6 +482,24 @@ __device__ __forceinline__ void sorted_insert(double (&key)[MAXN], double x) {
     for (int k = MAXN - 1; k >= 1; --k) key[k] = key_max(key[k - 1], key_min(key[k], x));
     key[0] = key_min(key[0], x);
 }
+#ifdef CA_STAMPS  // diagnostic build: per-wave cycle count of each phase (never in the product library)
+#if CA_STAMPS == 2   // wall-clock variant: the 100 MHz device-wide counter (wave timelines across CUs)
+#define CA_STAMP_CLOCK() __builtin_amdgcn_s_memrealtime()
+#else                // per-CU shader-clock counter (phase shares inside a wave)
+#define CA_STAMP_CLOCK() __builtin_amdgcn_s_memtime()
+#endif
+#define CA_STAMP(k)                                                                      \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        const unsigned long long _t = CA_STAMP_CLOCK();                                  \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                              \
+        if ((threadIdx.x & 63) == 0 && p.dbg)                                            \
+            p.dbg[((size_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6)) * 16 + (k)] = _t; \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define CA_STAMP(k) do { } while (0)
+#endif
 // ============================================================================================
 // Neighbour search for every agent (App. A.2): the obstacle edges within range and
 // the K nearest agents, written as the lists [A,S,N] / [A,K,N] that the solve kernel and the
@@ -503,6 +521,7 @@ __global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
     const int N = p.N, K = p.K, S = p.S;
     const int q = active ? a * N + i : 0;
     const int lbase = la << p.logP;
+    CA_STAMP(12);
     V2 pos = mk(0.0f, 0.0f);
     if (active) pos = mk(p.pos_x[q], p.pos_y[q]);
     s_px[tid] = pos.x; s_py[tid] = pos.y;
@@ -534,6 +553,7 @@ __global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
         }
     }
     const int ocnt = oin < S ? oin : S;
+    CA_STAMP(13);
 
     // ---- agent neighbours (App. A.2): K nearest within neighbor_dist, ties -> lower index ----
     const int kofs = KMAX - K;  // the K-entry list is right-aligned in the register array
@@ -556,6 +576,7 @@ __global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
         }
     }
 
+    CA_STAMP(14);
     if (active) {
         if (oin > S) atomicAdd(reinterpret_cast<int*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_OVERFLOW]), 1);
         p.nb_count[q] = ncnt;
@@ -567,6 +588,7 @@ __global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
         for (int k = 0; k < SMAX; ++k)
             if (k >= sofs) p.obst_idx[((size_t)a * S + (k - sofs)) * N + i] = key_index(okey[k]);
     }
+    CA_STAMP(15);
 }
 
 // LDS carve-up of the step kernel (bytes): lines | px py vx vy | misc ints
@@ -582,19 +604,6 @@ __host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S, int ST = 
 // actions != null : env.py:367-416 `step`;  actions == null : `orca_step` (env.py:447-450,
 // ALAN:631-636) followed by the done test of ALAN:118-121 unless CA_F_NODONE.
 // ============================================================================================
-#ifdef CA_STAMPS  // diagnostic build: per-wave cycle count of each phase (never in the product library)
-#define CA_STAMP(k)                                                                      \
-    do {                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                               \
-        const unsigned long long _t = __builtin_amdgcn_s_memtime();                      \
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                              \
-        if ((threadIdx.x & 63) == 0 && p.dbg)                                            \
-            p.dbg[((size_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6)) * 16 + (k)] = _t; \
-        __builtin_amdgcn_sched_barrier(0);                                               \
-    } while (0)
-#else
-#define CA_STAMP(k) do { } while (0)
-#endif
 
 // ST = 0: ORCA lines in the LDS table [K+S][BS] (any K <= 16, S <= 8).
 // ST > 0: ORCA lines in registers (ST obstacle slots + KMAX neighbour slots), LP2/LP1 fully unrolled,
@@ -1133,7 +1142,7 @@ struct ObsArgs {
 #define CA_OSTAMP(k)                                                                       \
     do {                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                 \
-        const unsigned long long _t = __builtin_amdgcn_s_memtime();                        \
+        const unsigned long long _t = CA_STAMP_CLOCK();                                    \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                \
         if ((threadIdx.x & 63) == 0 && p.dbg)                                              \
             p.dbg[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = _t; \
