@@ -33,6 +33,35 @@ def min_ttime(start_xy, goal_xy, max_speed=1.0):
     return ttime(max_speed * d)
 
 
+def load_actions(path):
+    """Read an action set written by the reference's trainer (`f.write(str(actions))`,
+    Train_ALAN_action_space.py:150-153: the repr of a list of (x, y) tuples, e.g. ALAN/crowd_actions.act)."""
+    import ast
+    with open(path) as f:
+        acts = ast.literal_eval(f.read().strip())
+    out = [(float(a[0]), float(a[1])) for a in acts]
+    if not out or len(out) > 32:
+        raise ValueError("%s: %d actions (supported: 1..32)" % (path, len(out)))
+    return out
+
+
+def save_actions(path, actions):
+    """The same format, for hand-over to the reference's own simulator."""
+    with open(path, "w") as f:
+        f.write(str([(float(a[0]), float(a[1])) for a in actions]))
+
+
+def evaluate_actions(actions, numAgents=50, scenario="crowd", num=3, mode=1, device=0, seed=0):
+    """Mean TTime of an action set over `num` random worlds -- what MCMC_trainer.evaluate_action
+    (Train_ALAN_action_space.py:53-66) computes with `num` reset()/run_sim() rounds in sequence -- as ONE
+    batched run: the `num` episodes are the arenas of one handle.  Returns (mean TTime, successes)."""
+    sim = Collision_Avoidance_Sim(numAgents=numAgents, scenario=scenario, online_actions=actions, device=device,
+                                  seed=seed, n_arenas=num)
+    ok, _, tt, _ = sim.run_sim(mode)
+    sim.vec.close()
+    return float(np.mean(tt)), int(np.sum(ok))
+
+
 class Collision_Avoidance_Sim(object):
     """Same constructor and run_sim()/reset() contract as ALAN_true.py:10-131 (no Tk window).
 
@@ -49,6 +78,7 @@ class Collision_Avoidance_Sim(object):
         self.default_online_actions = list(DEFAULT_ACTIONS)
         self.max_step = int((10 / self.timeStep) * numAgents)                       # ALAN_true.py:59
         self._device, self._seed, self.n_arenas = device, seed, int(n_arenas)
+        self._resets = 0
         self.vec = None
         self.reset(online_actions)
 
@@ -60,8 +90,12 @@ class Collision_Avoidance_Sim(object):
             self.vec.close()
         p = scenarios.alan_params(self.numAgents, self.scenario)
         self.envsize = scenarios.envsize(self.scenario, self.numAgents)
+        # every reset() is a new random world (ALAN_true.py:133-139 re-runs _init_world): the arenas of round r
+        # are the global arenas [r * n_arenas, (r + 1) * n_arenas) of this seed
         self.vec = VecCollisionAvoidanceEnv(self.n_arenas, self.numAgents, scenario=self.scenario, params=p,
-                                            device=self._device, seed=self._seed, use_torch=False)
+                                            device=self._device, seed=self._seed, use_torch=False,
+                                            arena_offset=self._resets * self.n_arenas)
+        self._resets += 1
         self.vec.alan_configure(self.online_actions, self.online_temp, self.timewindow, self.timeStep)
         self.step_count, self.TTime = 0, 0
         start = np.stack([self.vec.get(_lib.FLD_POS_X), self.vec.get(_lib.FLD_POS_Y)], -1)

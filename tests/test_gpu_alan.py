@@ -165,3 +165,26 @@ def test_sim_dropin_run_sim():
     okb, totb, ttb, mttb = batch.run_sim(1)
     assert okb.shape == (64,) and okb.all() and ttb[0] == tt and totb[0] == total and mttb[0] == mtt
     assert len(np.unique(totb)) > 8 and (ttb > 0).all()
+
+
+def test_reset_draws_a_new_world_and_batched_evaluation():
+    """reset() re-creates the world like ALAN_true.py:133-139; evaluate_actions() = MCMC_trainer.evaluate_action
+    (Train_ALAN_action_space.py:53-66) as one batched run."""
+    sim = alan.Collision_Avoidance_Sim(numAgents=8, scenario="crowd", seed=7)
+    p0 = sim.vec.get(_lib.FLD_POS_X).copy()
+    r1 = sim.run_sim(1)
+    sim.reset()
+    p1 = sim.vec.get(_lib.FLD_POS_X).copy()
+    r2 = sim.run_sim(1)
+    sim.reset([(1, 0), (0, 1)])
+    assert not np.array_equal(p0, p1) and r1 != r2 and sim.vec.n_actions == 2
+    # the three rounds of the trainer's evaluation == arenas 0..2 of one batched handle
+    acts = [(1, 0), (0.6, -0.8), (-0.5, 0.86)]
+    mean_tt, ok = alan.evaluate_actions(acts, numAgents=8, scenario="crowd", num=3, seed=7)
+    seq = alan.Collision_Avoidance_Sim(numAgents=8, scenario="crowd", online_actions=acts, seed=7)
+    tts = []
+    for r in range(3):
+        if r:
+            seq.reset(acts)
+        tts.append(seq.run_sim(1)[2])
+    assert ok == 3 and abs(mean_tt - float(np.mean(tts))) < 1e-12

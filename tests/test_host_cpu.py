@@ -95,3 +95,18 @@ def test_scenario_geometry():
     assert scenarios.alan_params(8, "circle")["max_step"] == int((10 / (1 / 60.)) * 8)
     with pytest.raises(ValueError):
         scenarios.obstacles("nope", 4)
+
+
+def test_action_set_files(tmp_path):
+    """.act files are the repr of a list of tuples (Train_ALAN_action_space.py:150-153)."""
+    from collision_avoidance_amd import alan
+    f = tmp_path / "crowd_actions.act"
+    f.write_text("[(1, 0), (0.06130798855686512, -0.9981188959934139), (-0.6767380373137093, 0.7362238985884584)]")
+    acts = alan.load_actions(str(f))
+    assert acts == [(1.0, 0.0), (0.06130798855686512, -0.9981188959934139), (-0.6767380373137093, 0.7362238985884584)]
+    g = tmp_path / "out.act"
+    alan.save_actions(str(g), acts)
+    assert alan.load_actions(str(g)) == acts
+    (tmp_path / "bad.act").write_text("[]")
+    with pytest.raises(ValueError):
+        alan.load_actions(str(tmp_path / "bad.act"))
