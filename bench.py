@@ -162,7 +162,7 @@ def main():
         achieved = agents * kbytes / (kms * 1e-3) / 1e9
         traffic = None
         try:  # HBM bytes per launch from this round's committed rocprofv3 --pmc passes of this command
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_h_hbm_traffic_pmc.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_u_hbm_traffic_pmc.json")))
             if args.workload == "C3" and full:
                 traffic = tj["kernels"][dom]["hbm_bytes_high"]
         except Exception:
