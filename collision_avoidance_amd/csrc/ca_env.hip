@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -47,6 +48,7 @@ struct ca_env {
     ObstDev* d_obst = nullptr;
     std::vector<ObstDev> h_obst;
     int P = 1, logP = 0, BS = 64, grid = 1, K = 0, S = 1;
+    int BSn = 64, grid_n = 1;  // the neighbour kernel's own workgroup size
     int ST = 0, KT = 16;  // solve-kernel variant: ST > 0 = register lines with ST obstacle slots; KT = KMAX
     size_t lds = 0;
     uint64_t steps_done = 0;  // env steps executed (agent_steps = steps_done * A * N)
@@ -182,24 +184,30 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.goal_x0 = c.goal_x0; a.goal_x1 = c.goal_x1; a.goal_y0 = c.goal_y0; a.goal_y1 = c.goal_y1;
 }
 
+template <int KMAX>
+static void launch_nbr_k(ca_env* e, const StepArgs& a) {
+    const dim3 grid(e->grid_n), block(e->BSn);
+    ProfScope ps(e, KIND_NBR);
+    switch (e->BSn) {
+        case 64: hipLaunchKernelGGL((nbr_kernel<KMAX, 64>), grid, block, 0, e->stream, a); break;
+        case 128: hipLaunchKernelGGL((nbr_kernel<KMAX, 128>), grid, block, 0, e->stream, a); break;
+        case 256: hipLaunchKernelGGL((nbr_kernel<KMAX, 256>), grid, block, 0, e->stream, a); break;
+        case 512: hipLaunchKernelGGL((nbr_kernel<KMAX, 512>), grid, block, 0, e->stream, a); break;
+        default: hipLaunchKernelGGL((nbr_kernel<KMAX, 1024>), grid, block, 0, e->stream, a); break;
+    }
+}
 template <int KMAX, int ST>
 static hipError_t launch_step_k(ca_env* e, const StepArgs& a) {
+    launch_nbr_k<KMAX>(e, a);  // neighbour search, then lines + LP + integration + reward/done on the same stream
     const dim3 grid(e->grid), block(e->BS);
-    switch (e->BS) {  // neighbour search, then lines + LP + integration + reward/done on the same stream
-#define CA_LAUNCH_PAIR(BSZ)                                                                          \
-    {                                                                                                \
-        { ProfScope ps(e, KIND_NBR);                                                                 \
-          hipLaunchKernelGGL((nbr_kernel<KMAX, BSZ>), grid, block, 0, e->stream, a); }               \
-        { ProfScope ps(e, KIND_STEP);                                                                \
-          hipLaunchKernelGGL((step_kernel<KMAX, BSZ, ST>), grid, block, e->lds, e->stream, a); }     \
+    ProfScope ps(e, KIND_STEP);
+    switch (e->BS) {
+        case 64: hipLaunchKernelGGL((step_kernel<KMAX, 64, ST>), grid, block, e->lds, e->stream, a); break;
+        case 128: hipLaunchKernelGGL((step_kernel<KMAX, 128, ST>), grid, block, e->lds, e->stream, a); break;
+        case 256: hipLaunchKernelGGL((step_kernel<KMAX, 256, ST>), grid, block, e->lds, e->stream, a); break;
+        case 512: hipLaunchKernelGGL((step_kernel<KMAX, 512, ST>), grid, block, e->lds, e->stream, a); break;
+        default: hipLaunchKernelGGL((step_kernel<KMAX, 1024, ST>), grid, block, e->lds, e->stream, a); break;
     }
-        case 64: CA_LAUNCH_PAIR(64) break;
-        case 128: CA_LAUNCH_PAIR(128) break;
-        case 256: CA_LAUNCH_PAIR(256) break;
-        case 512: CA_LAUNCH_PAIR(512) break;
-        default: CA_LAUNCH_PAIR(1024) break;
-    }
-#undef CA_LAUNCH_PAIR
     return hipGetLastError();
 }
 static hipError_t launch_step(ca_env* e, const StepArgs& a) {
@@ -373,6 +381,13 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     e->BS = P > 64 ? P : 64;
     const int apb = e->BS / P;
     e->grid = (cfg->n_arenas + apb - 1) / apb;
+    {
+        const char* v = getenv("CA_NBR_BS");  // diagnostic switch: power of two in [max(P, 64), 1024]
+        const int want = v ? atoi(v) : 0;
+        const bool ok = want >= 64 && want <= 1024 && (want & (want - 1)) == 0 && want >= P;
+        e->BSn = ok ? want : e->BS;
+        e->grid_n = (cfg->n_arenas + e->BSn / P - 1) / (e->BSn / P);
+    }
     e->K = cfg->max_neighbors;
     e->S = cfg->max_obst_neighbors;
     {   // solve-kernel variant: register-resident ORCA lines when the configuration fits its slots
@@ -408,7 +423,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     if (r == hipSuccess) r = dalloc(&e->obs, an * CA_OBS_DIM);
     if (r == hipSuccess) r = dalloc(&e->d_obst, (size_t)1);
 #ifdef CA_STAMPS
-    if (r == hipSuccess) r = dalloc(&e->dbg, (size_t)e->grid * (e->BS / 64) * 16);
+    if (r == hipSuccess) r = dalloc(&e->dbg, (size_t)std::max(e->grid * (e->BS / 64), e->grid_n * (e->BSn / 64)) * 16);
     if (r == hipSuccess) r = dalloc(&e->dbg_obs, (size_t)cfg->n_arenas * ((cfg->n_agents + 15) / 16 + 16) * 4 * 16);
 #endif
     if (r == hipSuccess && e->lds > 48 * 1024) {

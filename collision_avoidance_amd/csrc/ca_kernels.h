@@ -509,6 +509,12 @@ __device__ __forceinline__ void sorted_insert(double (&key)[MAXN], double x) {
 // ============================================================================================
 template <int KMAX, int BS>
 __global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
+#ifndef CA_NBR_NO_VGPR_PAD
+    // Claim 128 VGPRs (the kernel needs 56): at most 4 waves then fit on a SIMD, so a launch that brings one
+    // wave per SIMD slot (4096 x 64 lanes on 256 CUs) is spread evenly.  Without it the dispatcher puts
+    // anything from 1 to 7 of these light waves on a SIMD and the kernel waits for the fullest one.
+    asm volatile("" ::: "v127");
+#endif
     __shared__ float s_px[BS];
     __shared__ float s_py[BS];
     const int tid = threadIdx.x;
