@@ -1363,6 +1363,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     // per pair and every chord is accept-tested against the pair's single ray.  Only accepted chords
     // (about two per pair) are re-derived through build()/hit() for the exact hit distance.
     const int np = s_cnt[g];
+    const float tol = 1e-5f * p.rays[0] * (p.rays[0] + 2.0f * p.radius + 1.0f);  // rays[0] = neighbor_dist (env.py:321-332)
     for (int pi = r; pi < np; pi += 16) {
         const int pr = s_pair[g * OBS_PAIRCAP + pi];
         const int k = pr >> 4, ray = pr & 15;
@@ -1381,18 +1382,22 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
                 const float x1 = oc.x + rx, y1 = oc.y + ry;
                 vx[e] = c * x1 - s * y1; vy[e] = s * x1 + c * y1;      // utils.py:59 (= utils.py:60 of chord e-1)
             }
+            // Which chords can the exact test accept?  It needs the crossing parameter along the chord,
+            // s_numer / denom (utils.py:21-31), inside [0, 1], i.e. the ray's LINE must separate the chord's end
+            // points.  cr[e] = ray x vertex e is bit for bit -s_numer of chord e (s02 = 0 - r1 is an exact
+            // negation), so one cross product per VERTEX decides all eight chords: a chord whose two end
+            // points lie on the same side of the line by more than `tol` (50x the worst rounding error of the
+            // three cross products involved) cannot be accepted.  The survivors -- the entry and the exit
+            // chord, a third one when the line grazes a vertex -- go through the reference's arithmetic below.
+            float cr[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cr[e] = s10x * vy[e] - s10y * vx[e];
             unsigned acc = 0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float r1x = vx[e], r1y = vy[e], r2x = vx[(e + 1) & 7], r2y = vy[(e + 1) & 7];
-                const float s32x = r2x - r1x, s32y = r2y - r1y, s02x = 0.0f - r1x, s02y = 0.0f - r1y;
-                const float t_numer = s32x * s02y - s32y * s02x;
-                const float denom = s10x * s32y - s32x * s10y;            // utils.py:14
-                const float s_numer = s10x * s02y - s10y * s02x;          // utils.py:21
-                const bool dpos = denom > 0.0f;
-                const bool ok = (denom != 0.0f) && ((s_numer < 0.0f) != dpos) && ((t_numer < 0.0f) != dpos) &&
-                                ((s_numer > denom) != dpos) && ((t_numer > denom) != dpos);  // utils.py:15-31
-                acc |= ok ? (1u << e) : 0u;
+                const float ca = cr[e], cb = cr[(e + 1) & 7];
+                const bool same_side = (ca > tol && cb > tol) || (ca < -tol && cb < -tol);
+                acc |= same_side ? 0u : (1u << e);
             }
             while (acc) {  // ascending chord index, strict '<': the first minimum wins
                 const int e = __ffs(acc) - 1;
