@@ -1171,10 +1171,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 constexpr int OBS_PAIRCAP = 16 * (16 + 8);  // (source, ray) pairs of one agent: <= 16 rays x (K + S) sources
 
 // LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | nb idx [16][16] | obstacle idx [16][8]
-//              | ray and octagon tables [64] | pair counts [16] | (source, ray) pair lists [16][384] u16
+//              | ray and octagon tables [64] | pair counts [2][16] | (source, ray) pair lists [16][384] u16
+//              (a list holds the agent-neighbour pairs from its front and the obstacle pairs from its back)
 __host__ __device__ inline size_t obs_lds_bytes(int N, int obs_bs) {
     const size_t apb = obs_bs / 16;
-    return (size_t)N * 16 + apb * 16 * 8 + apb * 16 * 4 + apb * 8 * 4 + 64 * 4 + apb * 4 + apb * OBS_PAIRCAP * 2;
+    return (size_t)N * 16 + apb * 16 * 8 + apb * 16 * 4 + apb * 8 * 4 + 64 * 4 + 2 * apb * 4 + apb * OBS_PAIRCAP * 2;
 }
 #ifndef CA_OBS_BS_MAX
 #define CA_OBS_BS_MAX 256
@@ -1238,8 +1239,9 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     int* s_ob = s_nb + OBS_APB * 16;
     float* s_rays = reinterpret_cast<float*>(s_ob + OBS_APB * 8);  // [32] rays then [32] octagon
     float* s_oct = s_rays + 32;
-    int* s_cnt = reinterpret_cast<int*>(s_oct + 32);                       // [16] pairs per agent
-    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_cnt + OBS_APB);  // [16][OBS_PAIRCAP]
+    int* s_cnt = reinterpret_cast<int*>(s_oct + 32);                       // [16] neighbour pairs per agent
+    int* s_cnt2 = s_cnt + OBS_APB;                                         // [16] obstacle pairs per agent
+    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_cnt2 + OBS_APB);  // [16][OBS_PAIRCAP]
     CA_OSTAMP(0);
     if (tid < 32) { s_rays[tid] = p.rays[tid]; s_oct[tid] = p.oct[tid]; }
 
@@ -1256,7 +1258,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         if (r < ns) s_ob[g * 8 + r] = p.obst_idx[((size_t)a * S + r) * N + i];
     }
     s_key[g * 16 + r] = ~0ull;
-    if (r == 0) s_cnt[g] = 0;
+    if (r == 0) { s_cnt[g] = 0; s_cnt2[g] = 0; }
     CA_OSTAMP(1);
     __syncthreads();
     CA_OSTAMP(2);
@@ -1264,51 +1266,52 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     const int M = 8 * nn + ns;
     float mx = 0.0f, my = 0.0f;
     if (M > 0) { mx = s_px[i]; my = s_py[i]; }
-    // ---- pre-pass, lane per NEIGHBOUR / OBSTACLE EDGE: the rays that can reach it ("ray window").
-    // Agent neighbour: all 8 octagon vertices lie on the circle of radius R around it, so the rays
-    // within asin(R/d) of its direction are a superset for each of its 8 chords (margin 0.02 dial
-    // units = 7.8e-3 rad).  Obstacle edge: the angular span of its two end points (see "Ray windows").
-    // Both cases evaluate the dial of two points, so the lanes share one instruction stream.
-    for (int k = r; k < nn + ns; k += 16) {
-        float ax, ay, bx, by;
-        bool all;
-        const bool is_nb = k < nn;
-        if (is_nb) {
-            const int nb = s_nb[g * 16 + k];
-            const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
-            const float d2 = rx * rx + ry * ry, R = p.radius;
-            ax = c * rx - s * ry; ay = s * rx + c * ry;
-            bx = __builtin_amdgcn_sqrtf(fmaxf(d2 - R * R, 0.0f)); by = -R;  // dial(b) = atan2(R, sqrt(d2-R2))
-            all = !(d2 > 1.0404f * R * R);  // the agent is inside (or within 2 % of) that circle
-        } else {
-            const ObstDev o1 = load_obst(p.obst, s_ob[g * 8 + (k - nn)]);
-            const float x1 = o1.px - mx, y1 = o1.py - my, x2 = o1.qx - mx, y2 = o1.qy - my;
-            ax = c * x1 - s * y1; ay = s * x1 + c * y1;
-            bx = c * x2 - s * y2; by = s * x2 + c * y2;
-            const float n2 = ax * ax + ay * ay, n3 = bx * bx + by * by;
-            all = !(fminf(n2, n3) > 1e-6f * fmaxf(n2, n3)) || !(fminf(n2, n3) > 1e-12f);
-        }
-        const float ua = ray_dial(ax, ay), ub = ray_dial(bx, by);
-        float lo, hi;
-        if (is_nb) {
-            lo = ua - ub - 0.02f; hi = ua + ub + 0.02f;
-        } else {
-            float du = ub - ua;
-            du = (du > 8.0f) ? du - 16.0f : du;
-            du = (du <= -8.0f) ? du + 16.0f : du;
-            all = all || (fabsf(du) > 7.8f);
-            lo = ua + fminf(du, 0.0f) - 0.01f; hi = ua + fmaxf(du, 0.0f) + 0.01f;
-        }
-        int i0 = (int)ceilf(lo), i1 = (int)floorf(hi);
+    // ---- pre-pass: which (source, ray) pairs are worth the exact test?  Supersets only; never results. ----
+    // (1) lane per agent NEIGHBOUR: all 8 octagon vertices lie on the circle of radius R around it, so the
+    // rays within asin(R/d) of its direction are a superset for each of its 8 chords.  asin(t) <= t + (pi/2 - 1) t^3
+    // on [0, 1] ((asin t - t) / t^3 grows from 1/6 to pi/2 - 1); margin 0.02 dial units = 7.8e-3 rad covers the
+    // dial's 1e-4 and the approximate reciprocal square root.
+    for (int k = r; k < nn; k += 16) {
+        const int nb = s_nb[g * 16 + k];
+        const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
+        const float d2 = rx * rx + ry * ry, R = p.radius;
+        const float ax = c * rx - s * ry, ay = s * rx + c * ry;
+        const bool all = !(d2 > 1.0404f * R * R);  // the agent is inside (or within 2 % of) that circle
+        const float ua = ray_dial(ax, ay);
+        const float t = R * __builtin_amdgcn_rsqf(d2);
+        const float hw = t * (1.0f + 0.5708f * (t * t)) * 2.54647908947f + 0.02f;
+        int i0 = (int)ceilf(ua - hw), i1 = (int)floorf(ua + hw);
         if (all || i1 - i0 >= 15) { i0 = 0; i1 = 15; }
-        // emit one (source, ray) pair per ray of the window (the list order is irrelevant: results are
-        // merged with a commutative minimum)
         const int w = i1 - i0 + 1;
-        if (w > 0) {
+        if (w > 0) {  // neighbour pairs fill the list from the front (list order is irrelevant: commutative minimum)
             const int base = atomicAdd(&s_cnt[g], w);
-            for (int t = 0; t < w; ++t)
-                s_pair[g * OBS_PAIRCAP + base + t] = (unsigned short)((k << 4) | ((i0 + t) & 15));
+            for (int t2 = 0; t2 < w; ++t2)
+                s_pair[g * OBS_PAIRCAP + base + t2] = (unsigned short)((k << 4) | ((i0 + t2) & 15));
         }
+    }
+    // (2) lane per RAY, one obstacle edge at a time: the exact test can accept a ray only if the ray's line
+    // separates the edge's end points and the crossing is not behind the origin, i.e. (up to rounding, covered
+    // by tolE = 50x the error of these products) the two end points are not on the same side of the line and
+    // not both behind.  Obstacle pairs fill the agent's list from the back.
+    {
+        const float dx = s_rays[2 * r], dy = s_rays[2 * r + 1];
+        int cnt2 = 0;
+        for (int sidx = 0; sidx < ns; ++sidx) {
+            const ObstDev o1 = load_obst(p.obst, s_ob[g * 8 + sidx]);
+            const float x1 = o1.px - mx, y1 = o1.py - my, x2 = o1.qx - mx, y2 = o1.qy - my;
+            const float ax = c * x1 - s * y1, ay = s * x1 + c * y1;
+            const float bx = c * x2 - s * y2, by = s * x2 + c * y2;
+            const float c2 = dx * ay - dy * ax, c3 = dx * by - dy * bx;
+            const float f2 = dx * ax + dy * ay, f3 = dx * bx + dy * by;
+            const float tolE = 1e-5f * p.rays[0] * (fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by) + 1.0f);
+            const bool keep = !(c2 > tolE && c3 > tolE) && !(c2 < -tolE && c3 < -tolE) && (fmaxf(f2, f3) >= -tolE);
+            const unsigned grp = (unsigned)(__ballot(keep) >> (threadIdx.x & 48)) & 0xFFFFu;  // my agent's 16 lanes
+            if (keep)
+                s_pair[g * OBS_PAIRCAP + OBS_PAIRCAP - 1 - (cnt2 + __popc(grp & ((1u << r) - 1u)))] =
+                    (unsigned short)(((nn + sidx) << 4) | r);
+            cnt2 += __popc(grp);
+        }
+        if (r == 0) s_cnt2[g] = cnt2;
     }
     CA_OSTAMP(3);
     wave_lds_sync();  // the 16 lanes of an agent are in one wave: no workgroup barrier needed
@@ -1357,13 +1360,34 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         return true;
     };
 
+    // the same test and distance without early exits (the division of a rejected chord is computed and dropped)
+    auto hit_nb = [&](const SegGeom& sg, float s10x, float s10y, float& d) -> bool {
+        const float denom = s10x * sg.s32y - sg.s32x * s10y;          // utils.py:14
+        const float s_numer = s10x * sg.s02y - s10y * sg.s02x;        // utils.py:21
+        const bool dpos = denom > 0.0f;
+        const bool ok = (denom != 0.0f) && ((s_numer < 0.0f) != dpos) && ((sg.t_numer < 0.0f) != dpos) &&
+                        ((s_numer > denom) != dpos) && ((sg.t_numer > denom) != dpos);  // utils.py:15-31
+        const float t = sg.t_numer / denom;                            // utils.py:34
+        const float hx = 0.0f + t * s10x, hy = 0.0f + t * s10y;        // utils.py:36-37
+        d = sqrtf(hx * hx + hy * hy);                                  // utils.py:38
+        return ok;
+    };
+
     // ---- phase A: lane per (source, ray) pair ----
     // An agent neighbour contributes the 8 chords of its octagon; consecutive chords share an end point
     // bit for bit (env.py:335-350 builds them as a chain), so the 8 rotated vertices are computed once
     // per pair and every chord is accept-tested against the pair's single ray.  Only accepted chords
     // (about two per pair) are re-derived through build()/hit() for the exact hit distance.
-    const int np = s_cnt[g];
     const float tol = 1e-5f * p.rays[0] * (p.rays[0] + 2.0f * p.radius + 1.0f);  // rays[0] = neighbor_dist (env.py:321-332)
+    auto merge = [&](int ray, float best, int best_m) {
+        if (best_m >= 0) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)best_m;
+            atomicMin(&s_key[g * 16 + ray], key);
+        }
+    };
+    // (neighbour, ray) pairs and (obstacle edge, ray) pairs in loops of their own: a wave that mixes the two
+    // kinds in one pass pays for both code paths
+    const int np = s_cnt[g];
     for (int pi = r; pi < np; pi += 16) {
         const int pr = s_pair[g * OBS_PAIRCAP + pi];
         const int k = pr >> 4, ray = pr & 15;
@@ -1372,48 +1396,61 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         int best_m = -1;
         SegGeom sg;
         float dum0, dum1, d, hx, hy;
-        if (k < nn) {
-            const int nb = s_nb[g * 16 + k];
-            const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
-            float vx[8], vy[8];
+        const int nb = s_nb[g * 16 + k];
+        const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
+        float vx[8], vy[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
-                const float x1 = oc.x + rx, y1 = oc.y + ry;
-                vx[e] = c * x1 - s * y1; vy[e] = s * x1 + c * y1;      // utils.py:59 (= utils.py:60 of chord e-1)
-            }
-            // Which chords can the exact test accept?  It needs the crossing parameter along the chord,
-            // s_numer / denom (utils.py:21-31), inside [0, 1], i.e. the ray's LINE must separate the chord's end
-            // points.  cr[e] = ray x vertex e is bit for bit -s_numer of chord e (s02 = 0 - r1 is an exact
-            // negation), so one cross product per VERTEX decides all eight chords: a chord whose two end
-            // points lie on the same side of the line by more than `tol` (50x the worst rounding error of the
-            // three cross products involved) cannot be accepted.  The survivors -- the entry and the exit
-            // chord, a third one when the line grazes a vertex -- go through the reference's arithmetic below.
-            float cr[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) cr[e] = s10x * vy[e] - s10y * vx[e];
-            unsigned acc = 0;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float ca = cr[e], cb = cr[(e + 1) & 7];
-                const bool same_side = (ca > tol && cb > tol) || (ca < -tol && cb < -tol);
-                acc |= same_side ? 0u : (1u << e);
-            }
-            while (acc) {  // ascending chord index, strict '<': the first minimum wins
-                const int e = __ffs(acc) - 1;
-                acc &= acc - 1;
-                build(8 * k + e, sg, dum0, dum1, false);
-                if (hit(sg, s10x, s10y, d, hx, hy) && d < best) { best = d; best_m = 8 * k + e; }
-            }
-        } else {
-            const int m = 8 * nn + (k - nn);
-            build(m, sg, dum0, dum1, false);
-            if (hit(sg, s10x, s10y, d, hx, hy)) { best = d; best_m = m; }
+        for (int e = 0; e < 8; ++e) {
+            const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
+            const float x1 = oc.x + rx, y1 = oc.y + ry;
+            vx[e] = c * x1 - s * y1; vy[e] = s * x1 + c * y1;      // utils.py:59 (= utils.py:60 of chord e-1)
         }
-        if (best_m >= 0) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)best_m;
-            atomicMin(&s_key[g * 16 + ray], key);
+        // Which chords can the exact test accept?  It needs the crossing parameter along the chord,
+        // s_numer / denom (utils.py:21-31), inside [0, 1], i.e. the ray's LINE must separate the chord's end
+        // points.  cr[e] = ray x vertex e is bit for bit -s_numer of chord e (s02 = 0 - r1 is an exact
+        // negation), so one cross product per VERTEX decides all eight chords: a chord whose two end
+        // points lie on the same side of the line by more than `tol` (50x the worst rounding error of the
+        // three cross products involved) cannot be accepted.  The survivors -- the entry and the exit
+        // chord, a third one when the line grazes a vertex -- go through the reference's arithmetic below.
+        float cr[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cr[e] = s10x * vy[e] - s10y * vx[e];
+        unsigned acc = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ca = cr[e], cb = cr[(e + 1) & 7];
+            const bool same_side = (ca > tol && cb > tol) || (ca < -tol && cb < -tol);
+            acc |= same_side ? 0u : (1u << e);
         }
+        // ascending chord index, strict '<': the first minimum wins.  Two surviving chords (entry and exit)
+        // are evaluated side by side in straight-line code, so that the two instruction streams can share
+        // packed fp32 instructions; the arithmetic of each is the reference's (utils.py:14-38).
+        while (acc) {
+            const int e1 = __ffs(acc) - 1;
+            acc &= acc - 1;
+            const bool two = acc != 0;
+            const int e2 = two ? __ffs(acc) - 1 : e1;
+            acc &= acc - 1;  // (0 & anything stays 0)
+            SegGeom g1, g2;
+            build(8 * k + e1, g1, dum0, dum1, false);
+            build(8 * k + e2, g2, dum0, dum1, false);
+            float d1, d2;
+            const bool ok1 = hit_nb(g1, s10x, s10y, d1), ok2 = hit_nb(g2, s10x, s10y, d2) && two;
+            if (ok1 && d1 < best) { best = d1; best_m = 8 * k + e1; }
+            if (ok2 && d2 < best) { best = d2; best_m = 8 * k + e2; }
+        }
+        merge(ray, best, best_m);
+    }
+    const int no = s_cnt2[g];
+    for (int pi = r; pi < no; pi += 16) {
+        const int pr = s_pair[g * OBS_PAIRCAP + OBS_PAIRCAP - 1 - pi];
+        const int k = pr >> 4, ray = pr & 15;
+        const float s10x = s_rays[2 * ray] - 0.0f, s10y = s_rays[2 * ray + 1] - 0.0f;
+        SegGeom sg;
+        float dum0, dum1, d, hx, hy;
+        const int m = 8 * nn + (k - nn);
+        build(m, sg, dum0, dum1, false);
+        if (hit(sg, s10x, s10y, d, hx, hy)) merge(ray, d, m);
     }
     CA_OSTAMP(5);
     wave_lds_sync();
