@@ -1170,12 +1170,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 512 or 1024 lanes, so that a workgroup can own a whole arena of up to 64 agents and stage it once).
 constexpr int OBS_PAIRCAP = 16 * (16 + 8);  // (source, ray) pairs of one agent: <= 16 rays x (K + S) sources
 
-// LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | nb idx [16][16] | obstacle idx [16][8]
+// LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | hit points [16][16] float2 | nb idx [16][16] | obstacle idx [16][8]
 //              | ray and octagon tables [64] | pair counts [2][16] | (source, ray) pair lists [16][384] u16
 //              (a list holds the agent-neighbour pairs from its front and the obstacle pairs from its back)
 __host__ __device__ inline size_t obs_lds_bytes(int N, int obs_bs) {
     const size_t apb = obs_bs / 16;
-    return (size_t)N * 16 + apb * 16 * 8 + apb * 16 * 4 + apb * 8 * 4 + 64 * 4 + 2 * apb * 4 + apb * OBS_PAIRCAP * 2;
+    return (size_t)N * 16 + 2 * apb * 16 * 8 + apb * 16 * 4 + apb * 8 * 4 + 64 * 4 + 2 * apb * 4 + apb * OBS_PAIRCAP * 2;
 }
 #ifndef CA_OBS_BS_MAX
 #define CA_OBS_BS_MAX 256
@@ -1235,7 +1235,8 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     float* s_vx = s_py + N;
     float* s_vy = s_vx + N;
     unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_vy + N);  // N*16 B: 8-aligned
-    int* s_nb = reinterpret_cast<int*>(s_key + OBS_APB * 16);
+    float2* s_hit = reinterpret_cast<float2*>(s_key + OBS_APB * 16);             // hit point of the key's chord
+    int* s_nb = reinterpret_cast<int*>(s_hit + OBS_APB * 16);
     int* s_ob = s_nb + OBS_APB * 16;
     float* s_rays = reinterpret_cast<float*>(s_ob + OBS_APB * 8);  // [32] rays then [32] octagon
     float* s_oct = s_rays + 32;
@@ -1361,14 +1362,14 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     };
 
     // the same test and distance without early exits (the division of a rejected chord is computed and dropped)
-    auto hit_nb = [&](const SegGeom& sg, float s10x, float s10y, float& d) -> bool {
+    auto hit_nb = [&](const SegGeom& sg, float s10x, float s10y, float& d, float& hx, float& hy) -> bool {
         const float denom = s10x * sg.s32y - sg.s32x * s10y;          // utils.py:14
         const float s_numer = s10x * sg.s02y - s10y * sg.s02x;        // utils.py:21
         const bool dpos = denom > 0.0f;
         const bool ok = (denom != 0.0f) && ((s_numer < 0.0f) != dpos) && ((sg.t_numer < 0.0f) != dpos) &&
                         ((s_numer > denom) != dpos) && ((sg.t_numer > denom) != dpos);  // utils.py:15-31
         const float t = sg.t_numer / denom;                            // utils.py:34
-        const float hx = 0.0f + t * s10x, hy = 0.0f + t * s10y;        // utils.py:36-37
+        hx = 0.0f + t * s10x; hy = 0.0f + t * s10y;                    // utils.py:36-37
         d = sqrtf(hx * hx + hy * hy);                                  // utils.py:38
         return ok;
     };
@@ -1379,10 +1380,14 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     // per pair and every chord is accept-tested against the pair's single ray.  Only accepted chords
     // (about two per pair) are re-derived through build()/hit() for the exact hit distance.
     const float tol = 1e-5f * p.rays[0] * (p.rays[0] + 2.0f * p.radius + 1.0f);  // rays[0] = neighbor_dist (env.py:321-332)
-    auto merge = [&](int ray, float best, int best_m) {
+    // The lane whose key is the ray's minimum after this trip's atomics leaves its hit point next to the key
+    // (the LDS executes one wave's instructions in order, so the re-read sees every lane's atomic of the trip;
+    // a later, smaller key overwrites both).  Phase B then needs no second division / square root.
+    auto merge = [&](int ray, float best, int best_m, float bhx, float bhy) {
         if (best_m >= 0) {
             const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)best_m;
             atomicMin(&s_key[g * 16 + ray], key);
+            if (s_key[g * 16 + ray] == key) s_hit[g * 16 + ray] = make_float2(bhx, bhy);
         }
     };
     // (neighbour, ray) pairs and (obstacle edge, ray) pairs in loops of their own: a wave that mixes the two
@@ -1392,10 +1397,9 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         const int pr = s_pair[g * OBS_PAIRCAP + pi];
         const int k = pr >> 4, ray = pr & 15;
         const float s10x = s_rays[2 * ray] - 0.0f, s10y = s_rays[2 * ray + 1] - 0.0f;
-        float best = __int_as_float(0x7f800000);
+        float best = __int_as_float(0x7f800000), bhx = 0.0f, bhy = 0.0f;
         int best_m = -1;
-        SegGeom sg;
-        float dum0, dum1, d, hx, hy;
+        float dum0, dum1;
         const int nb = s_nb[g * 16 + k];
         const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
         float vx[8], vy[8];
@@ -1434,12 +1438,12 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             SegGeom g1, g2;
             build(8 * k + e1, g1, dum0, dum1, false);
             build(8 * k + e2, g2, dum0, dum1, false);
-            float d1, d2;
-            const bool ok1 = hit_nb(g1, s10x, s10y, d1), ok2 = hit_nb(g2, s10x, s10y, d2) && two;
-            if (ok1 && d1 < best) { best = d1; best_m = 8 * k + e1; }
-            if (ok2 && d2 < best) { best = d2; best_m = 8 * k + e2; }
+            float d1, d2, h1x, h1y, h2x, h2y;
+            const bool ok1 = hit_nb(g1, s10x, s10y, d1, h1x, h1y), ok2 = hit_nb(g2, s10x, s10y, d2, h2x, h2y) && two;
+            if (ok1 && d1 < best) { best = d1; best_m = 8 * k + e1; bhx = h1x; bhy = h1y; }
+            if (ok2 && d2 < best) { best = d2; best_m = 8 * k + e2; bhx = h2x; bhy = h2y; }
         }
-        merge(ray, best, best_m);
+        merge(ray, best, best_m, bhx, bhy);
     }
     const int no = s_cnt2[g];
     for (int pi = r; pi < no; pi += 16) {
@@ -1450,7 +1454,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         float dum0, dum1, d, hx, hy;
         const int m = 8 * nn + (k - nn);
         build(m, sg, dum0, dum1, false);
-        if (hit(sg, s10x, s10y, d, hx, hy)) merge(ray, d, m);
+        if (hit(sg, s10x, s10y, d, hx, hy)) merge(ray, d, m, hx, hy);
     }
     CA_OSTAMP(5);
     wave_lds_sync();
@@ -1461,9 +1465,10 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     float bx = 0.0f, by = 0.0f, vx = 0.0f, vy = 0.0f;
     if (key != ~0ull) {
         SegGeom sg;
-        float wx, wy, d;
+        float wx, wy;
         build((int)(unsigned)key, sg, wx, wy, true);
-        hit(sg, s_rays[2 * r] - 0.0f, s_rays[2 * r + 1] - 0.0f, d, bx, by);
+        const float2 h = s_hit[g * 16 + r];
+        bx = h.x; by = h.y;
         if (!(bx == 0.0f && by == 0.0f)) { vx = wx; vy = wy; }  // utils.py:103
     }
     CA_OSTAMP(7);
