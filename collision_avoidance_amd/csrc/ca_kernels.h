@@ -1170,12 +1170,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 512 or 1024 lanes, so that a workgroup can own a whole arena of up to 64 agents and stage it once).
 constexpr int OBS_PAIRCAP = 16 * (16 + 8);  // (source, ray) pairs of one agent: <= 16 rays x (K + S) sources
 
-// LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | hit points [16][16] float2 | nb idx [16][16] | obstacle idx [16][8]
+// LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | hit points [16][16] float2 | agent frames [16] float4 | nb idx [16][16] | obstacle idx [16][8]
 //              | ray and octagon tables [64] | pair counts [2][16] | (source, ray) pair lists [16][384] u16
 //              (a list holds the agent-neighbour pairs from its front and the obstacle pairs from its back)
 __host__ __device__ inline size_t obs_lds_bytes(int N, int obs_bs) {
     const size_t apb = obs_bs / 16;
-    return (size_t)N * 16 + 2 * apb * 16 * 8 + apb * 16 * 4 + apb * 8 * 4 + 64 * 4 + 2 * apb * 4 + apb * OBS_PAIRCAP * 2;
+    return (size_t)N * 16 + 2 * apb * 16 * 8 + apb * 16 + apb * 16 * 4 + apb * 8 * 4 + 64 * 4 + 2 * apb * 4 + apb * OBS_PAIRCAP * 2;
 }
 #ifndef CA_OBS_BS_MAX
 #define CA_OBS_BS_MAX 256
@@ -1236,7 +1236,8 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     float* s_vy = s_vx + N;
     unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_vy + N);  // N*16 B: 8-aligned
     float2* s_hit = reinterpret_cast<float2*>(s_key + OBS_APB * 16);             // hit point of the key's chord
-    int* s_nb = reinterpret_cast<int*>(s_hit + OBS_APB * 16);
+    float4* s_frame = reinterpret_cast<float4*>(s_hit + OBS_APB * 16);           // (cos, sin, pos x, pos y) per agent
+    int* s_nb = reinterpret_cast<int*>(s_frame + OBS_APB);
     int* s_ob = s_nb + OBS_APB * 16;
     float* s_rays = reinterpret_cast<float*>(s_ob + OBS_APB * 8);  // [32] rays then [32] octagon
     float* s_oct = s_rays + 32;
@@ -1267,6 +1268,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     const int M = 8 * nn + ns;
     float mx = 0.0f, my = 0.0f;
     if (M > 0) { mx = s_px[i]; my = s_py[i]; }
+    if (r == 0) s_frame[g] = make_float4(c, s, mx, my);  // phase A lanes also work for the wave's other agents
     // ---- pre-pass: which (source, ray) pairs are worth the exact test?  Supersets only; never results. ----
     // (1) lane per agent NEIGHBOUR: all 8 octagon vertices lie on the circle of radius R around it, so the
     // rays within asin(R/d) of its direction are a superset for each of its 8 chords.  asin(t) <= t + (pi/2 - 1) t^3
@@ -1344,6 +1346,18 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             velx = rvx - sg.r1x; vely = rvy - sg.r1y;                      // utils.py:62
         }
     };
+    // chord e of neighbour slot k of agent ga (one of this wave's four), in ga's frame fr = (cos, sin, x, y)
+    auto build_nb = [&](int ga, const float4& fr, int k, int e, SegGeom& sg) {
+        const int nb = s_nb[ga * 16 + k];
+        const float rx = s_px[nb] - fr.z, ry = s_py[nb] - fr.w;
+        const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
+        const float x1 = oc.x + rx, y1 = oc.y + ry, x2 = oc.z + rx, y2 = oc.w + ry;
+        sg.r1x = fr.x * x1 - fr.y * y1; sg.r1y = fr.y * x1 + fr.x * y1;  // utils.py:59
+        sg.r2x = fr.x * x2 - fr.y * y2; sg.r2y = fr.y * x2 + fr.x * y2;  // utils.py:60
+        sg.s32x = sg.r2x - sg.r1x; sg.s32y = sg.r2y - sg.r1y;
+        sg.s02x = 0.0f - sg.r1x; sg.s02y = 0.0f - sg.r1y;
+        sg.t_numer = sg.s32x * sg.s02y - sg.s32y * sg.s02x;
+    };
     // utils.py:5-40 for the ray with end point (s10x, s10y) starting at the origin.  (Deferring the
     // division/sqrt/atomic of accepted pairs to a second loop over a hit bitmask, and a branch-free
     // accept test, were both measured SLOWER: 136-138 us vs 117 us at C3.)
@@ -1383,31 +1397,39 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     // The lane whose key is the ray's minimum after this trip's atomics leaves its hit point next to the key
     // (the LDS executes one wave's instructions in order, so the re-read sees every lane's atomic of the trip;
     // a later, smaller key overwrites both).  Phase B then needs no second division / square root.
-    auto merge = [&](int ray, float best, int best_m, float bhx, float bhy) {
+    auto merge = [&](int ga, int ray, float best, int best_m, float bhx, float bhy) {
         if (best_m >= 0) {
             const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)best_m;
-            atomicMin(&s_key[g * 16 + ray], key);
-            if (s_key[g * 16 + ray] == key) s_hit[g * 16 + ray] = make_float2(bhx, bhy);
+            atomicMin(&s_key[ga * 16 + ray], key);
+            if (s_key[ga * 16 + ray] == key) s_hit[ga * 16 + ray] = make_float2(bhx, bhy);
         }
     };
     // (neighbour, ray) pairs and (obstacle edge, ray) pairs in loops of their own: a wave that mixes the two
-    // kinds in one pass pays for both code paths
-    const int np = s_cnt[g];
-    for (int pi = r; pi < np; pi += 16) {
-        const int pr = s_pair[g * OBS_PAIRCAP + pi];
+    // kinds in one pass pays for both code paths.  The neighbour pairs of the wave's FOUR agents form one
+    // work list shared by its 64 lanes (an agent has 13 pairs on average but often a few more than 16, which
+    // would cost its 16 lanes -- and with them the wave -- a second trip).
+    const int g0 = g & ~3;
+    const int n0 = s_cnt[g0], n1 = s_cnt[g0 + 1], n2 = s_cnt[g0 + 2], n3 = s_cnt[g0 + 3];
+    const int ntot = n0 + n1 + n2 + n3;
+    for (int pi = tid & 63; pi < ntot; pi += 64) {
+        int ga = g0, li = pi;
+        { const bool b = li >= n0; ga = b ? g0 + 1 : ga; li = b ? li - n0 : li;
+          const bool b1 = b && li >= n1; ga = b1 ? g0 + 2 : ga; li = b1 ? li - n1 : li;
+          const bool b2 = b1 && li >= n2; ga = b2 ? g0 + 3 : ga; li = b2 ? li - n2 : li; }
+        const float4 fr = s_frame[ga];
+        const int pr = s_pair[ga * OBS_PAIRCAP + li];
         const int k = pr >> 4, ray = pr & 15;
         const float s10x = s_rays[2 * ray] - 0.0f, s10y = s_rays[2 * ray + 1] - 0.0f;
         float best = __int_as_float(0x7f800000), bhx = 0.0f, bhy = 0.0f;
         int best_m = -1;
-        float dum0, dum1;
-        const int nb = s_nb[g * 16 + k];
-        const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
+        const int nb = s_nb[ga * 16 + k];
+        const float rx = s_px[nb] - fr.z, ry = s_py[nb] - fr.w;
         float vx[8], vy[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
             const float x1 = oc.x + rx, y1 = oc.y + ry;
-            vx[e] = c * x1 - s * y1; vy[e] = s * x1 + c * y1;      // utils.py:59 (= utils.py:60 of chord e-1)
+            vx[e] = fr.x * x1 - fr.y * y1; vy[e] = fr.y * x1 + fr.x * y1;  // utils.py:59 (= utils.py:60 of chord e-1)
         }
         // Which chords can the exact test accept?  It needs the crossing parameter along the chord,
         // s_numer / denom (utils.py:21-31), inside [0, 1], i.e. the ray's LINE must separate the chord's end
@@ -1436,14 +1458,14 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             const int e2 = two ? __ffs(acc) - 1 : e1;
             acc &= acc - 1;  // (0 & anything stays 0)
             SegGeom g1, g2;
-            build(8 * k + e1, g1, dum0, dum1, false);
-            build(8 * k + e2, g2, dum0, dum1, false);
+            build_nb(ga, fr, k, e1, g1);
+            build_nb(ga, fr, k, e2, g2);
             float d1, d2, h1x, h1y, h2x, h2y;
             const bool ok1 = hit_nb(g1, s10x, s10y, d1, h1x, h1y), ok2 = hit_nb(g2, s10x, s10y, d2, h2x, h2y) && two;
             if (ok1 && d1 < best) { best = d1; best_m = 8 * k + e1; bhx = h1x; bhy = h1y; }
             if (ok2 && d2 < best) { best = d2; best_m = 8 * k + e2; bhx = h2x; bhy = h2y; }
         }
-        merge(ray, best, best_m, bhx, bhy);
+        merge(ga, ray, best, best_m, bhx, bhy);
     }
     const int no = s_cnt2[g];
     for (int pi = r; pi < no; pi += 16) {
@@ -1454,7 +1476,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         float dum0, dum1, d, hx, hy;
         const int m = 8 * nn + (k - nn);
         build(m, sg, dum0, dum1, false);
-        if (hit(sg, s10x, s10y, d, hx, hy)) merge(ray, d, m, hx, hy);
+        if (hit(sg, s10x, s10y, d, hx, hy)) merge(g, ray, d, m, hx, hy);
     }
     CA_OSTAMP(5);
     wave_lds_sync();
