@@ -154,15 +154,18 @@ def main():
         kbytes_of = {"nbr_kernel": 0, "step_kernel": BYTES_STEP_KERNEL_FULL if full else BYTES_STEP_KERNEL_ORCA,
                      "obs_kernel": BYTES_OBS_KERNEL}
         kms_of = {k: v[1] for k, v in ktimes.items() if v[0] > 0 and k in kbytes_of}
-        dom = max(kms_of, key=kms_of.get)          # the kernel with the longest average launch
+        # dominant kernel: the longest average launch among the kernels that own algorithmic HBM bytes
+        # (nbr_kernel has none); launches within 3 % of the longest count as a tie, decided by the bytes moved
+        longest = max(v for k, v in kms_of.items() if kbytes_of[k] > 0)
+        dom = max((k for k in kms_of if kbytes_of[k] > 0 and kms_of[k] >= 0.97 * longest), key=lambda k: kbytes_of[k])
         kms, kbytes = kms_of[dom], kbytes_of[dom]
-        if kbytes == 0:                              # nbr_kernel has no algorithmic HBM bytes of its own
-            dom = max((k for k in kms_of if kbytes_of[k] > 0), key=kms_of.get)
-            kms, kbytes = kms_of[dom], kbytes_of[dom]
         achieved = agents * kbytes / (kms * 1e-3) / 1e9
+        per_kernel = {k: {"algorithmic_GB_per_s": agents * kbytes_of[k] / (v * 1e-3) / 1e9,
+                          "frac": agents * kbytes_of[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                      for k, v in kms_of.items() if kbytes_of[k] > 0}
         traffic = None
         try:  # HBM bytes per launch from this round's committed rocprofv3 --pmc passes of this command
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_u_hbm_traffic_pmc.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_v_hbm_traffic_pmc.json")))
             if args.workload == "C3" and full:
                 traffic = tj["kernels"][dom]["hbm_bytes_high"]
         except Exception:
@@ -180,7 +183,7 @@ def main():
                        "mode": args.mode, "sharding": "arenas, %d per GPU" % A},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_agent": kbytes, "kernel_ms": kms},
+                         "algorithmic_bytes_per_agent": kbytes, "kernel_ms": kms, "per_kernel": per_kernel},
             "kernels_ms": dict({k: round(v, 5) for k, v in kms_of.items()}, sum=round(sum(kms_of.values()), 5),
                                wall_per_step=dt / args.steps * 1e3),
             "full_step_algorithmic": {"bytes_per_agent": 316 if full else 52,
