@@ -45,33 +45,43 @@ def parse():
 
 
 def cpu_baseline(workload, mode, seconds):
-    """The CPU oracle (a serial C++ restatement of the same path, 1 core) on a bounded sample of
-    the same workload: 64 arenas of the same scenario, stepped until `seconds` have elapsed."""
+    """The CPU oracle (a C++ restatement of the same path) on a bounded sample of the same workload: arenas of the
+    same scenario stepped for about `seconds`, first on one core, then on all cores of this process's share of
+    the host (arenas dealt to threads).  `value` is the multi-core rate, `cores` the threads used."""
     from collision_avoidance_amd import scenarios
     from oracle import oracle as o
     from tests import helpers as H
     w = scenarios.BENCH_CONFIGS[workload]
     N = w["n_agents"]
-    A = max(1, min(64, 4096 // N))
-    p = scenarios.bench_params(N, w["neighbor_dist"], w["max_neighbors"])
-    env = H.make_oracle(A, N, "crowd", p, seed=0)
+    try:
+        cores = max(1, min(32, len(os.sched_getaffinity(0))))
+    except Exception:
+        cores = max(1, min(32, os.cpu_count() or 1))
     rng = np.random.RandomState(0)
-    acts = rng.uniform(-0.5, 0.5, (8, A, N)).astype(np.float32)
-    for s in range(3):
-        env.step(acts[s], flags=o.F_OBS) if mode == "step" else env.orca_step(flags=0)
-    t0 = time.perf_counter()
-    steps = 0
-    while time.perf_counter() - t0 < seconds:
-        for s in range(5):
-            if mode == "step":
-                env.step(acts[(steps + s) % 8], flags=o.F_OBS)
-            else:
-                env.orca_step(flags=0)
-        steps += 5
-    dt = time.perf_counter() - t0
-    return {"value": A * N * steps / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d arenas x %d agents x %d steps of the same workload (%s mode), oracle/ca_oracle.cpp "
-                      "-O2 serial, %.1f s" % (A, N, steps, mode, dt)}
+
+    def run(A, threads, budget):
+        p = scenarios.bench_params(N, w["neighbor_dist"], w["max_neighbors"])
+        env = H.make_oracle(A, N, "crowd", p, seed=0)
+        acts = rng.uniform(-0.5, 0.5, (8, A, N)).astype(np.float32)
+        flags = o.F_OBS if mode == "step" else 0
+        for s in range(3):
+            env.step_mt(acts[s] if mode == "step" else None, flags=flags, n_threads=threads)
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < budget:
+            for s in range(5):
+                env.step_mt(acts[(steps + s) % 8] if mode == "step" else None, flags=flags, n_threads=threads)
+            steps += 5
+        dt = time.perf_counter() - t0
+        return A * N * steps / dt, steps, dt
+
+    A1 = max(1, min(64, 4096 // N))
+    v1, s1, d1 = run(A1, 1, seconds * 0.4)
+    Am = max(cores, min(16 * cores, (4096 // N) * cores // 4 or cores))
+    vm, sm, dm = run(Am, cores, seconds * 0.6)
+    return {"value": vm, "unit": "agent-steps/s", "cores": cores, "kind": "port", "single_core_value": v1,
+            "sample": "%d arenas x %d agents x %d steps on %d threads (%.1f s) and %d arenas x %d steps on one (%.1f s), "
+                      "same workload (%s mode), oracle/ca_oracle.cpp -O2" % (Am, N, sm, cores, dm, A1, s1, d1, mode)}
 
 
 def main():

@@ -1323,6 +1323,21 @@ int orc_env_orca_step(void* env, uint32_t flags, int32_t prec) {
     return 0;
 }
 
+/* one env step with the arenas dealt to n_threads threads (arenas never interact): the multi-core CPU baseline */
+int orc_env_step_mt(void* env, const float* actions, uint32_t flags, int32_t prec, int32_t n_threads) {
+    Env* e = (Env*)env;
+    const int A = e->A();
+    if (n_threads <= 1) {
+        for (int a = 0; a < A; ++a) arena_step(*e, a, actions, flags, prec);
+        return 0;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t)
+        th.emplace_back([=]() { for (int a = t; a < A; a += n_threads) arena_step(*e, a, actions, flags, prec); });
+    for (auto& t : th) t.join();
+    return 0;
+}
+
 int orc_env_rollout(void* env, int32_t steps, uint32_t flags, int32_t n_threads) {
     Env* e = (Env*)env;
     const int A = e->A();

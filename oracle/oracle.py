@@ -75,6 +75,7 @@ def lib():
     L.orc_env_get.argtypes = [vp, i32, vp, sz]
     L.orc_env_reset.argtypes = [vp, vp, vp, u32, i32]
     L.orc_env_reset_masked.argtypes = [vp, vp, u32, i32]
+    L.orc_env_step_mt.argtypes = [vp, vp, u32, i32, i32]
     L.orc_env_step.argtypes = [vp, vp, u32, i32]
     L.orc_env_orca_step.argtypes = [vp, u32, i32]
     L.orc_env_rollout.argtypes = [vp, i32, u32, i32]
@@ -215,6 +216,14 @@ class OracleEnv:
     def step(self, actions, flags=F_OBS, prec=PREC_F32):
         a = np.ascontiguousarray(np.asarray(actions, np.float32).reshape(self.A, self.N))
         assert self.L.orc_env_step(self.h, _ptr(a), flags, prec) == 0
+
+    def step_mt(self, actions, flags=F_OBS, prec=PREC_F32, n_threads=1):
+        """step (actions given) or orca_step (actions None) on n_threads host threads."""
+        if actions is None:
+            assert self.L.orc_env_step_mt(self.h, None, flags, prec, n_threads) == 0
+        else:
+            a = np.ascontiguousarray(np.asarray(actions, np.float32).reshape(self.A, self.N))
+            assert self.L.orc_env_step_mt(self.h, _ptr(a), flags, prec, n_threads) == 0
 
     def orca_step(self, flags=0, prec=PREC_F32):
         assert self.L.orc_env_orca_step(self.h, flags, prec) == 0

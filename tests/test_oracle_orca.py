@@ -198,3 +198,24 @@ def test_process_obstacles_cuts_crossing_edges():
         d = pts[t["next"]] - pts
         u = d / np.linalg.norm(d, axis=1, keepdims=True)
         assert np.abs(u - np.stack([t["ux"], t["uy"]], 1)).max() < 1e-5      # cut pieces keep the edge direction
+
+
+def test_threaded_step_equals_serial():
+    """orc_env_step_mt (the multi-core CPU baseline of bench.py) deals arenas to threads; arenas never interact,
+    so the result is the serial one bit for bit."""
+    from collision_avoidance_amd import scenarios
+    p = scenarios.bench_params(16, 5.0, 10)
+
+    def make():
+        e = o.OracleEnv(o.make_config(n_arenas=12, n_agents=16, seed=3, max_obst_neighbors=4, **p))
+        e.set_obstacles(scenarios.obstacles("crowd", 16)); e.init_scenario(o.SCN_CROWD)
+        return e
+    a, b = make(), make()
+    rng = np.random.RandomState(0)
+    for s in range(40):
+        act = rng.uniform(-1, 1, (12, 16)).astype(np.float32)
+        a.step(act, flags=o.F_OBS | o.F_STATS)
+        b.step_mt(act, flags=o.F_OBS | o.F_STATS, n_threads=5)
+    for f in (o.FLD_POS_X, o.FLD_VEL_Y, o.FLD_OBS, o.FLD_REWARD, o.FLD_GOAL_X, o.FLD_REGOAL_COUNT):
+        np.testing.assert_array_equal(a.get(f), b.get(f))
+    assert a.stats() == b.stats()
