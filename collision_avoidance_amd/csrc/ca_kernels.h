@@ -260,6 +260,109 @@ __device__ __forceinline__ int lp2_reg(const float4 (&L)[ML], int no, int ncnt, 
     return fail;
 }
 
+// Orders the LDS traffic of ONE wave: LDS executes a wave's instructions in issue order, so lanes of
+// the same wave only need the compiler not to move accesses across this point and the earlier
+// operations to have been issued and returned (s_waitcnt lgkmcnt(0)).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int POOL_SLOTS = 16;  // LP3 pool slots per wave (lanes beyond that take another round)
+
+// App. A.5 LP3, FOUR LANES PER AGENT.  LP3 is needed by ~9 % of the agents of a dense crowd, i.e. by five or six
+// lanes of every wave, while it is the longest dependent computation of the step: solved one agent per lane it
+// keeps a wave busy at a tenth of its width.  Here the agents that need it sit in the wave's LDS pool (lines,
+// projected lines and a header per slot) and lanes 4 s .. 4 s + 3 work for slot s:
+//   * the projected lines of a violated line i are built four at a time and compacted in order (ballot rank);
+//   * LP2 over them stays sequential, but each LP1 inside it -- the clipping of line ii against the ii lines
+//     before it -- is dealt to the four lanes and merged: tLeft is a maximum, tRight a minimum and the failure
+//     flag an OR of per-line conditions, all independent of the order, so the merged values are bit for bit
+//     those of the serial loop (whose running `tLeft > tRight` test equals the test on the final values,
+//     because tLeft only grows and tRight only shrinks).
+// Every lane of a group holds the same `result`; arithmetic per line is that of lp1()/lp3() above.
+// header of slot s: pool[(2 ML - 1) * POOL_SLOTS + s] = (result.x, result.y, bits(n | numObst << 8 | begin << 16), -)
+__device__ __noinline__ void lp3_coop(float4* pool, int ML, int nslots, float radius) {
+    const int lane = threadIdx.x & 63, slot = lane >> 2, q = lane & 3;
+    float4* hdr = pool + (size_t)(2 * ML - 1) * POOL_SLOTS;
+    LdsLines ls; ls.base = pool + slot; ls.stride = POOL_SLOTS;
+    LdsLines pj; pj.base = pool + (size_t)ML * POOL_SLOTS + slot; pj.stride = POOL_SLOTS;
+    const bool live = slot < nslots;
+    const float4 h = live ? hdr[slot] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int packed = __float_as_int(h.z);
+    const int n = live ? (packed & 0xFF) : 0, numObst = (packed >> 8) & 0xFF, begin = (packed >> 16) & 0xFF;
+    const int gshift = lane & ~3;
+    V2 result = mk(h.x, h.y);
+    float distance = 0.0f;
+    for (int i = begin; i < n; ++i) {
+        const Line Li = ls.get(i);
+        if (det(Li.dir, Li.point - result) > distance) {
+            for (int j = q; j < numObst; j += 4) pj.put(j, ls.get(j));
+            int m = numObst;
+            for (int j0 = numObst; j0 < i; j0 += 4) {
+                const int j = j0 + q;
+                bool valid = j < i;
+                Line l; l.point = mk(0.0f, 0.0f); l.dir = mk(1.0f, 0.0f);
+                if (valid) {
+                    const Line Lj = ls.get(j);
+                    const float d = det(Li.dir, Lj.dir);
+                    if (fabsf(d) <= EPS) {
+                        if (dot(Li.dir, Lj.dir) > 0.0f) valid = false;
+                        else l.point = 0.5f * (Li.point + Lj.point);
+                    } else {
+                        l.point = Li.point + (det(Lj.dir, Li.point - Lj.point) / d) * Li.dir;
+                    }
+                    l.dir = normalize(Lj.dir - Li.dir);
+                }
+                const unsigned mask = (unsigned)(__ballot(valid) >> gshift) & 0xFu;
+                if (valid) pj.put(m + __popc(mask & ((1u << q) - 1u)), l);
+                m += __popc(mask);
+            }
+            wave_lds_sync();
+            const V2 opt = mk(-Li.dir.y, Li.dir.x);
+            V2 res = opt * radius;  // lp2(..., dirOpt = true)
+            bool ok = true;
+            for (int ii = 0; ii < m && ok; ++ii) {
+                const Line L = pj.get(ii);
+                if (det(L.dir, L.point - res) > 0.0f) {
+                    const float dp = dot(L.point, L.dir);
+                    const float disc = sqr(dp) + sqr(radius) - absSq(L.point);
+                    int failed = disc < 0.0f ? 1 : 0;
+                    const float sq = sqrtf(disc);
+                    float tLeft = -dp - sq;
+                    float tRight = -dp + sq;
+                    for (int jj = q; jj < ii; jj += 4) {
+                        const Line M = pj.get(jj);
+                        const float den = det(L.dir, M.dir);
+                        const float num = det(M.dir, L.point - M.point);
+                        const bool par = fabsf(den) <= EPS;
+                        const float t = num / den;
+                        const bool right = !par && den >= 0.0f, left = !par && !(den >= 0.0f);
+                        tRight = (right && t < tRight) ? t : tRight;
+                        tLeft = (left && tLeft < t) ? t : tLeft;
+                        failed |= (par && num < 0.0f) ? 1 : 0;
+                    }
+#pragma unroll
+                    for (int x = 1; x <= 2; x <<= 1) {
+                        const float oR = __shfl_xor(tRight, x), oL = __shfl_xor(tLeft, x);
+                        tRight = (oR < tRight) ? oR : tRight;
+                        tLeft = (tLeft < oL) ? oL : tLeft;
+                        failed |= __shfl_xor(failed, x);
+                    }
+                    if (failed || tLeft > tRight) ok = false;  // lp2 stops here and LP3 keeps its previous result
+                    else res = (dot(opt, L.dir) > 0.0f) ? L.point + tRight * L.dir : L.point + tLeft * L.dir;
+                }
+            }
+            if (ok) result = res;
+            distance = det(Li.dir, Li.point - result);
+            wave_lds_sync();  // the projected lines are rewritten for the next violated line
+        }
+    }
+    if (live && q == 0) hdr[slot] = make_float4(result.x, result.y, h.z, 0.0f);
+}
+
 // App. A.5 LP3 with both line tables in an LDS pool slot (see the solve kernel)
 __device__ __noinline__ void lp3_pool(LdsLines ls, LdsLines pj, int n, int numObst, int begin, float radius, V2& result) {
     float distance = 0.0f;
@@ -287,8 +390,6 @@ __device__ __noinline__ void lp3_pool(LdsLines ls, LdsLines pj, int n, int numOb
         }
     }
 }
-constexpr int POOL_SLOTS = 16;  // LP3 pool slots per wave (lanes beyond that take another round)
-
 // App. A.4: the half-plane induced by one neighbouring agent (both agents have radius R)
 __device__ __forceinline__ Line agent_orca_line(V2 pos, V2 vel, V2 opos, V2 ovel, float R, float invT, float invDt) {
     const V2 rp = opos - pos;
@@ -599,9 +700,9 @@ __global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
 
 // LDS carve-up of the step kernel (bytes): lines | px py vx vy | misc ints
 // ST = 0: the LDS line table; ST > 0 (register lines): per wave an LP3 pool of POOL_SLOTS slots x
-// (ML lines + ML - 1 projected lines), ML = ST + KMAX
+// (ML lines + ML - 1 projected lines + a header), ML = ST + KMAX
 __host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S, int ST = 0, int KMAX = 0) {
-    if (ST > 0) return (size_t)(BS / 64) * (2 * (ST + KMAX) - 1) * POOL_SLOTS * 16 + (size_t)BS * 32;
+    if (ST > 0) return (size_t)(BS / 64) * (2 * (ST + KMAX)) * POOL_SLOTS * 16 + (size_t)BS * 32;
     return (size_t)BS * ((size_t)(K + S) * 16 + 16 + 16);
 }
 
@@ -633,9 +734,9 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     const int q = active ? a * N + i : 0;
     const int lbase = la << p.logP;
 
-    float4* s_lines = smem4;  // ST = 0: [(K+S)][BS];  ST > 0: [waves][2 ML - 1][POOL_SLOTS]
+    float4* s_lines = smem4;  // ST = 0: [(K+S)][BS];  ST > 0: [waves][2 ML][POOL_SLOTS] (last row: slot headers)
     float* s_px = reinterpret_cast<float*>(
-        smem4 + (ST > 0 ? (size_t)(BS / 64) * (2 * ML - 1) * POOL_SLOTS : (size_t)(K + S) * BS));
+        smem4 + (ST > 0 ? (size_t)(BS / 64) * (2 * ML) * POOL_SLOTS : (size_t)(K + S) * BS));
     float* s_py = s_px + BS;
     float* s_vx = s_py + BS;
     float* s_vy = s_vx + BS;
@@ -736,22 +837,31 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
         // ---- LP3 for the lanes whose LP2 was infeasible: they copy their lines into a slot of the
         // wave's LDS pool and solve there; more than POOL_SLOTS such lanes take further rounds ----
         {
-            float4* pool = s_lines + (size_t)(tid >> 6) * (2 * ML - 1) * POOL_SLOTS;
+            float4* pool = s_lines + (size_t)(tid >> 6) * (2 * ML) * POOL_SLOTS;
+            float4* hdr = pool + (size_t)(2 * ML - 1) * POOL_SLOTS;
             bool need = active && fail < nl;
             const unsigned long long below = (1ull << (tid & 63)) - 1ull;
             while (true) {
                 const unsigned long long m = __ballot(need);
                 if (!m) break;
                 const int rank = __popcll(m & below);
-                if (need && rank < POOL_SLOTS) {
+                const bool mine = need && rank < POOL_SLOTS;
+                if (mine) {
                     LdsLines pls; pls.base = pool + rank; pls.stride = POOL_SLOTS;
-                    LdsLines ppj; ppj.base = pool + (size_t)ML * POOL_SLOTS + rank; ppj.stride = POOL_SLOTS;
                     static_for<ML>([&](auto kc) __attribute__((always_inline)) {
                         constexpr int k = decltype(kc)::value;
                         const bool valid = (k < ST) ? (k < no) : (k - ST < ncnt);
                         if (valid) pls.base[((k < ST) ? k : no + (k - ST)) * POOL_SLOTS] = L[k];
                     });
-                    lp3_pool(pls, ppj, nl, no, fail, p.max_speed, nv);
+                    hdr[rank] = make_float4(nv.x, nv.y, __int_as_float(nl | (no << 8) | (fail << 16)), 0.0f);
+                }
+                wave_lds_sync();
+                const int waiting = __popcll(m);
+                lp3_coop(pool, ML, waiting < POOL_SLOTS ? waiting : POOL_SLOTS, p.max_speed);  // the whole wave works
+                wave_lds_sync();
+                if (mine) {
+                    const float4 h = hdr[rank];
+                    nv = mk(h.x, h.y);
                     need = false;
                 }
             }
@@ -1157,15 +1267,6 @@ struct ObsArgs {
 #else
 #define CA_OSTAMP(k) do { } while (0)
 #endif
-// Orders the LDS traffic of ONE wave: LDS executes a wave's instructions in issue order, so lanes of
-// the same wave only need the compiler not to move accesses across this point and the earlier
-// operations to have been issued and returned (s_waitcnt lgkmcnt(0)).
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 // The observation workgroup: OBS_BS lanes = OBS_BS/16 agents of ONE arena (template parameter: 256,
 // 512 or 1024 lanes, so that a workgroup can own a whole arena of up to 64 agents and stage it once).
 constexpr int OBS_PAIRCAP = 16 * (16 + 8);  // (source, ray) pairs of one agent: <= 16 rays x (K + S) sources
