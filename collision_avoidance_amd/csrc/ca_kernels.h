@@ -363,33 +363,6 @@ __device__ __noinline__ void lp3_coop(float4* pool, int ML, int nslots, float ra
     if (live && q == 0) hdr[slot] = make_float4(result.x, result.y, h.z, 0.0f);
 }
 
-// App. A.5 LP3 with both line tables in an LDS pool slot (see the solve kernel)
-__device__ __noinline__ void lp3_pool(LdsLines ls, LdsLines pj, int n, int numObst, int begin, float radius, V2& result) {
-    float distance = 0.0f;
-    for (int i = begin; i < n; ++i) {
-        const Line Li = ls.get(i);
-        if (det(Li.dir, Li.point - result) > distance) {
-            int m = 0;
-            for (int j = 0; j < numObst; ++j) { const Line l0 = ls.get(j); pj.put(m++, l0); }
-            for (int j = numObst; j < i; ++j) {
-                const Line Lj = ls.get(j);
-                Line l;
-                const float d = det(Li.dir, Lj.dir);
-                if (fabsf(d) <= EPS) {
-                    if (dot(Li.dir, Lj.dir) > 0.0f) continue;
-                    l.point = 0.5f * (Li.point + Lj.point);
-                } else {
-                    l.point = Li.point + (det(Lj.dir, Li.point - Lj.point) / d) * Li.dir;
-                }
-                l.dir = normalize(Lj.dir - Li.dir);
-                pj.put(m++, l);
-            }
-            const V2 tmp = result;
-            if (lp2(pj, m, radius, mk(-Li.dir.y, Li.dir.x), true, result) < m) result = tmp;
-            distance = det(Li.dir, Li.point - result);
-        }
-    }
-}
 // App. A.4: the half-plane induced by one neighbouring agent (both agents have radius R)
 __device__ __forceinline__ Line agent_orca_line(V2 pos, V2 vel, V2 opos, V2 ovel, float R, float invT, float invDt) {
     const V2 rp = opos - pos;
