@@ -641,7 +641,79 @@ __global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) nkey[k] = (k < kofs) ? KEY_DUMMY : KEY_EMPTY;
     int ncnt = 0;
-    if (K > 0) {
+    bool scanned = false;
+    if constexpr (BS >= 256) {
+        // Large arenas (one arena per workgroup, >= 192 agents): a uniform grid with cells at least neighbor_dist
+        // wide, rebuilt in LDS every step (counting sort of the agent indices by cell), so that an agent scans
+        // the 3 x 3 cells around it -- three contiguous runs of the sorted list -- instead of the whole arena.
+        // The cells are visited in no particular index order, so a candidate enters on `distance <= current
+        // K-th distance` and the 64-bit (distance, index) keys settle ties; the list is the same K smallest
+        // keys within neighbor_dist that the index-order scan keeps.
+        if (P == BS && N >= 192 && K > 0) {
+            __shared__ unsigned s_box[4];          // ordered-uint images of min x, min y, max x, max y
+            __shared__ int s_ccnt[256];            // agents per cell
+            __shared__ int s_cstart[257];          // first position of a cell in s_sorted
+            __shared__ unsigned short s_sorted[BS];
+            auto ord = [](float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+            auto unord = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); };
+            if (tid < 2) s_box[tid] = 0xFFFFFFFFu;
+            if (tid >= 2 && tid < 4) s_box[tid] = 0u;
+            if (tid < 256) s_ccnt[tid] = 0;
+            __syncthreads();
+            const bool in_arena = (a < p.a1) && (i < N);  // frozen arenas skip the scan but keep the barriers
+            if (in_arena) {
+                atomicMin(&s_box[0], ord(pos.x)); atomicMin(&s_box[1], ord(pos.y));
+                atomicMax(&s_box[2], ord(pos.x)); atomicMax(&s_box[3], ord(pos.y));
+            }
+            __syncthreads();
+            const float x0 = unord(s_box[0]), y0 = unord(s_box[1]);
+            const float ex = unord(s_box[2]) - x0, ey = unord(s_box[3]) - y0;
+            const float cs = fmaxf(p.neighbor_dist, fmaxf(ex, ey) * (1.0f / 15.5f));  // at most 16 x 16 cells
+            const float ics = 1.0f / cs;
+            const int Gx = min(16, (int)(ex * ics) + 1), Gy = min(16, (int)(ey * ics) + 1);
+            const int cx = min(Gx - 1, max(0, (int)((pos.x - x0) * ics))), cy = min(Gy - 1, max(0, (int)((pos.y - y0) * ics)));
+            int rank = 0;
+            if (in_arena) rank = atomicAdd(&s_ccnt[cy * Gx + cx], 1);
+            __syncthreads();
+            if (tid < 64) {  // exclusive prefix sum over the (<= 256) cells: four cells per lane of the first wave
+                const int c0 = s_ccnt[4 * tid], c1 = s_ccnt[4 * tid + 1], c2 = s_ccnt[4 * tid + 2], c3 = s_ccnt[4 * tid + 3];
+                int incl = c0 + c1 + c2 + c3;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int t = __shfl_up(incl, off);
+                    if (tid >= off) incl += t;
+                }
+                const int b = incl - (c0 + c1 + c2 + c3);
+                s_cstart[4 * tid] = b; s_cstart[4 * tid + 1] = b + c0; s_cstart[4 * tid + 2] = b + c0 + c1;
+                s_cstart[4 * tid + 3] = b + c0 + c1 + c2;
+                if (tid == 63) s_cstart[256] = incl;
+            }
+            __syncthreads();
+            if (in_arena) s_sorted[s_cstart[cy * Gx + cx] + rank] = (unsigned short)i;
+            __syncthreads();
+            const float rangeSq0 = sqr(p.neighbor_dist);
+            float rangeK = rangeSq0;  // distance of the current K-th entry once the list is full
+            for (int ry = -1; ry <= 1; ++ry) {
+                const int row = cy + ry;
+                int lo = 0, hi = 0;
+                if (active && row >= 0 && row < Gy) {
+                    lo = s_cstart[row * Gx + max(cx - 1, 0)];
+                    hi = s_cstart[row * Gx + min(cx + 1, Gx - 1) + 1];
+                }
+                for (int t = lo; t < hi; ++t) {
+                    const int j = s_sorted[t];
+                    const float dsq = absSq(pos - mk(s_px[j], s_py[j]));
+                    if (j != i && dsq < rangeSq0 && dsq <= rangeK) {
+                        sorted_insert<KMAX>(nkey, make_key(dsq, j));
+                        if (ncnt < K) ++ncnt;
+                        if (ncnt == K) rangeK = key_dist(nkey[KMAX - 1]);
+                    }
+                }
+            }
+            scanned = true;
+        }
+    }
+    if (K > 0 && !scanned) {
         float rangeSq = sqr(p.neighbor_dist);
         V2 o_next = mk(s_px[lbase], s_py[lbase]);
         for (int j = 0; j < N; ++j) {

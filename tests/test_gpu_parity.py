@@ -85,6 +85,11 @@ CASES = [
     # the largest workgroup shapes: 1024 lanes (register lines) and the LDS line table with K = 16
     ("n1000", 1, 1000, "crowd", dict(), 12, 6),
     ("n250k16", 2, 250, "crowd", dict(max_neighbors=16, neighbor_dist=4.0), 20, 10),
+    # the uniform-grid neighbour scan (>= 192 agents per arena): exact distance ties by symmetry (circle), a world
+    # whose bounding box is not the arena (incoming platoon), a small neighbour range (many cells)
+    ("grid_circle", 2, 256, "circle", dict(), 40, 10),
+    ("grid_incoming", 2, 226, "incoming", dict(), 60, 20),
+    ("grid_smallrange", 2, 400, "crowd", dict(neighbor_dist=1.5, max_neighbors=5), 40, 10),
 ]
 
 
