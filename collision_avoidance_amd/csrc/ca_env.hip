@@ -49,6 +49,7 @@ struct ca_env {
     std::vector<ObstDev> h_obst;
     int P = 1, logP = 0, BS = 64, grid = 1, K = 0, S = 1;
     int BSn = 64, grid_n = 1;  // the neighbour kernel's own workgroup size
+    bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
     int ST = 0, KT = 16;  // solve-kernel variant: ST > 0 = register lines with ST obstacle slots; KT = KMAX
     size_t lds = 0;
     uint64_t steps_done = 0;  // env steps executed (agent_steps = steps_done * A * N)
@@ -196,19 +197,23 @@ static void launch_nbr_k(ca_env* e, const StepArgs& a) {
         default: hipLaunchKernelGGL((nbr_kernel<KMAX, 1024>), grid, block, 0, e->stream, a); break;
     }
 }
-template <int KMAX, int ST>
-static hipError_t launch_step_k(ca_env* e, const StepArgs& a) {
-    launch_nbr_k<KMAX>(e, a);  // neighbour search, then lines + LP + integration + reward/done on the same stream
+template <int KMAX, int ST, bool FUSE>
+static hipError_t launch_step_kf(ca_env* e, const StepArgs& a) {
+    if (!FUSE) launch_nbr_k<KMAX>(e, a);  // neighbour search as a launch of its own (diagnostic: CA_FUSE_NBR=0)
     const dim3 grid(e->grid), block(e->BS);
     ProfScope ps(e, KIND_STEP);
-    switch (e->BS) {
-        case 64: hipLaunchKernelGGL((step_kernel<KMAX, 64, ST>), grid, block, e->lds, e->stream, a); break;
-        case 128: hipLaunchKernelGGL((step_kernel<KMAX, 128, ST>), grid, block, e->lds, e->stream, a); break;
-        case 256: hipLaunchKernelGGL((step_kernel<KMAX, 256, ST>), grid, block, e->lds, e->stream, a); break;
-        case 512: hipLaunchKernelGGL((step_kernel<KMAX, 512, ST>), grid, block, e->lds, e->stream, a); break;
-        default: hipLaunchKernelGGL((step_kernel<KMAX, 1024, ST>), grid, block, e->lds, e->stream, a); break;
+    switch (e->BS) {  // (neighbour search +) lines + LP + integration + reward/done
+        case 64: hipLaunchKernelGGL((step_kernel<KMAX, 64, ST, FUSE>), grid, block, e->lds, e->stream, a); break;
+        case 128: hipLaunchKernelGGL((step_kernel<KMAX, 128, ST, FUSE>), grid, block, e->lds, e->stream, a); break;
+        case 256: hipLaunchKernelGGL((step_kernel<KMAX, 256, ST, FUSE>), grid, block, e->lds, e->stream, a); break;
+        case 512: hipLaunchKernelGGL((step_kernel<KMAX, 512, ST, FUSE>), grid, block, e->lds, e->stream, a); break;
+        default: hipLaunchKernelGGL((step_kernel<KMAX, 1024, ST, FUSE>), grid, block, e->lds, e->stream, a); break;
     }
     return hipGetLastError();
+}
+template <int KMAX, int ST>
+static hipError_t launch_step_k(ca_env* e, const StepArgs& a) {
+    return e->fuse_nbr ? launch_step_kf<KMAX, ST, true>(e, a) : launch_step_kf<KMAX, ST, false>(e, a);
 }
 static hipError_t launch_step(ca_env* e, const StepArgs& a) {
     if (e->ST > 0) return e->KT == 5 ? launch_step_k<5, 4>(e, a) : launch_step_k<10, 4>(e, a);
@@ -219,7 +224,10 @@ static hipError_t launch_step(ca_env* e, const StepArgs& a) {
 
 template <int KMAX, int BS, int ST>
 static hipError_t set_lds_attr(size_t lds) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KMAX, BS, ST>),
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KMAX, BS, ST, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (r != hipSuccess) return r;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KMAX, BS, ST, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 template <int KMAX, int ST>
@@ -387,6 +395,8 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         const bool ok = want >= 64 && want <= 1024 && (want & (want - 1)) == 0 && want >= P;
         e->BSn = ok ? want : e->BS;
         e->grid_n = (cfg->n_arenas + e->BSn / P - 1) / (e->BSn / P);
+        const char* f = getenv("CA_FUSE_NBR");  // diagnostic switch: 0 = separate neighbour kernel
+        e->fuse_nbr = !(f && f[0] == '0') && e->BSn == e->BS;
     }
     e->K = cfg->max_neighbors;
     e->S = cfg->max_obst_neighbors;

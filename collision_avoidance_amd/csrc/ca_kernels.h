@@ -582,7 +582,7 @@ __device__ __forceinline__ void sorted_insert(double (&key)[MAXN], double x) {
 // its 16 B x (K+S) line table per lane.
 // ============================================================================================
 template <int KMAX, int BS>
-__global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
+__device__ __forceinline__ void nbr_body(const StepArgs& p) {
 #ifndef CA_NBR_NO_VGPR_PAD
     // Claim 128 VGPRs (the kernel needs 56): at most 4 waves then fit on a SIMD, so a launch that brings one
     // wave per SIMD slot (4096 x 64 lanes on 256 CUs) is spread evenly.  Without it the dispatcher puts
@@ -743,6 +743,11 @@ __global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
     CA_STAMP(15);
 }
 
+template <int KMAX, int BS>
+__global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
+    nbr_body<KMAX, BS>(p);
+}
+
 // LDS carve-up of the step kernel (bytes): lines | px py vx vy | misc ints
 // ST = 0: the LDS line table; ST > 0 (register lines): per wave an LP3 pool of POOL_SLOTS slots x
 // (ML lines + ML - 1 projected lines + a header), ML = ST + KMAX
@@ -762,9 +767,13 @@ __host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S, int ST = 
 //         LP3 through a small per-wave LDS pool.  Needs S <= ST; ~8 KB of LDS per wave instead of
 //         16 KB; built for 4 waves per SIMD (<= 128 VGPRs), i.e. 16 waves per CU: the 4096 arenas
 //         of the C3 workload are all resident at once instead of taking 1.6 rounds at 10 per CU.
-template <int KMAX, int BS, int ST>
+template <int KMAX, int BS, int ST, bool FUSE>
 __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs p) {
     extern __shared__ float4 smem4[];
+    // FUSE: the neighbour search runs at the head of this kernel instead of in a launch of its own (one
+    // drain/fill less per step, and its dispatch skew overlaps useful work).  A lane later reads back only the
+    // lists of its own agent, which it wrote itself; the search's LDS arrays are not used again.
+    if constexpr (FUSE) nbr_body<KMAX, BS>(p);
     constexpr int ML = ST + KMAX;  // register slots (ST > 0)
     const int tid = threadIdx.x;
     const int P = p.P;
