@@ -31,6 +31,8 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `pytho
                "reported, hbm_bytes_high doubles it (gfx950 tallies the 128-B requests of wide coalesced reads at 64 B)",
        "launches_per_pass": {"fetch": n1, "write": n2}, "kernels": {}}
 for k in ("nbr_kernel", "step_kernel", "obs_kernel"):
+    if k not in fetch or k not in write:   # the neighbour search is normally fused into step_kernel
+        continue
     f, w = fetch[k]["FETCH_SIZE"], write[k]["WRITE_SIZE"]
     out["kernels"][k] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_low": (f + w) * 1024,
                          "hbm_bytes_high": (2 * f + w) * 1024, "algorithmic_bytes": alg[k]}
