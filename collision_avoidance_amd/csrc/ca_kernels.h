@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     // bit for bit (env.py:335-350 builds them as a chain), so the 8 rotated vertices are computed once
     // per pair and every chord is accept-tested against the pair's single ray.  Only accepted chords
     // (about two per pair) are re-derived through build()/hit() for the exact hit distance.
-    const float tol = 1e-5f * p.rays[0] * (p.rays[0] + 2.0f * p.radius + 1.0f);  // rays[0] = neighbor_dist (env.py:321-332)
+    const float tol = 2e-5f * p.rays[0] * (p.rays[0] + 2.0f * p.radius + 1.0f);  // rays[0] = neighbor_dist (env.py:321-332)
     // The lane whose key is the ray's minimum after this trip's atomics leaves its hit point next to the key
     // (the LDS executes one wave's instructions in order, so the re-read sees every lane's atomic of the trip;
     // a later, smaller key overwrites both).  Phase B then needs no second division / square root.
@@ -1579,23 +1579,22 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         int best_m = -1;
         const int nb = s_nb[ga * 16 + k];
         const float rx = s_px[nb] - fr.z, ry = s_py[nb] - fr.w;
-        float vx[8], vy[8];
+        // Which chords can the exact test accept?  It needs the crossing parameter along the chord,
+        // s_numer / denom (utils.py:21-31), inside [0, 1], i.e. the ray's LINE must separate the chord's end
+        // points: with cr[e] = ray x vertex e (= -s_numer of chord e), a chord whose two end points lie on the
+        // same side of the line by more than `tol` cannot be accepted.  The filter does not need the reference's
+        // rounding, so it takes the cross products in the WORLD frame, where the octagon's vertices are constants:
+        // ray_w x (oct_e + rel) with ray_w the ray turned back by the agent's frame -- no vertex is rotated here.
+        // `tol` is 100x the rounding error of either form.  The survivors -- the entry and the exit chord, a
+        // third one when the line grazes a vertex -- go through the reference's arithmetic below.
+        const float wx = fr.x * s10x + fr.y * s10y, wy = fr.x * s10y - fr.y * s10x;
+        const float wb = wx * ry - wy * rx;
+        float cr[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
-            const float x1 = oc.x + rx, y1 = oc.y + ry;
-            vx[e] = fr.x * x1 - fr.y * y1; vy[e] = fr.y * x1 + fr.x * y1;  // utils.py:59 (= utils.py:60 of chord e-1)
+            cr[e] = (wx * oc.y - wy * oc.x) + wb;
         }
-        // Which chords can the exact test accept?  It needs the crossing parameter along the chord,
-        // s_numer / denom (utils.py:21-31), inside [0, 1], i.e. the ray's LINE must separate the chord's end
-        // points.  cr[e] = ray x vertex e is bit for bit -s_numer of chord e (s02 = 0 - r1 is an exact
-        // negation), so one cross product per VERTEX decides all eight chords: a chord whose two end
-        // points lie on the same side of the line by more than `tol` (50x the worst rounding error of the
-        // three cross products involved) cannot be accepted.  The survivors -- the entry and the exit
-        // chord, a third one when the line grazes a vertex -- go through the reference's arithmetic below.
-        float cr[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cr[e] = s10x * vy[e] - s10y * vx[e];
         unsigned acc = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
