@@ -407,10 +407,12 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->ST = (allow && e->K <= 10 && e->S <= 4) ? 4 : 0;
     }
     e->lds = step_lds_bytes(e->BS, e->K, e->S, e->ST, e->KT);
-    if (e->lds > 160 * 1024) {
+    // + the statically allocated LDS of the fused neighbour search: positions, and for >= 256 lanes the grid tables
+    const size_t lds_static = (size_t)e->BS * 8 + (e->BS >= 256 ? (size_t)e->BS * 2 + 16 + 1024 + 1028 : 0) + 64;
+    if (e->lds + lds_static > 160 * 1024) {
         fail(nullptr, CA_ERANGE, "ca_create: the solve kernel would need %zu B of LDS (> 160 KiB) for n_agents=%d, "
              "max_neighbors=%d, max_obst_neighbors=%d: arenas above 256 agents need max_neighbors <= 10 and "
-             "max_obst_neighbors <= 4 (register-line variant)", e->lds, cfg->n_agents, e->K, e->S);
+             "max_obst_neighbors <= 4 (register-line variant)", e->lds + lds_static, cfg->n_agents, e->K, e->S);
         if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
         delete e;
         return CA_ERANGE;
