@@ -1,0 +1,101 @@
+// ca_common.h -- shared types, launch arguments and small device helpers
+// Part of the HIP kernels of libcaenv.so (see ca_kernels.h for the overview and the numerics contract).
+#pragma once
+#include "ca_math.h"
+#include <utility>
+
+namespace ca {
+
+constexpr int SMAX = 8;       // CA_MAX_OBST_NEIGHBORS
+constexpr float EPS = 0.00001f;
+
+struct ObstDev {  // one obstacle edge (this vertex -> next vertex) with everything ORCA needs about
+                  // its two end vertices, so that no dependent `next`/`prev` gathers are required
+    float px, py, ux, uy;    // this vertex, unit direction of this edge
+    float qx, qy, qux, quy;  // next vertex, unit direction of the edge leaving it
+    float pux, puy;          // unit direction of the edge arriving at this vertex (prev's unitDir)
+    int next, prev;
+    int convex, qconvex, pad0, pad1;
+};
+static_assert(sizeof(ObstDev) == 64, "edge record is one 64-byte line");
+
+struct Line {
+    V2 point, dir;
+};
+
+struct StepArgs {
+    float *pos_x, *pos_y, *vel_x, *vel_y, *pref_x, *pref_y;
+    double *goal_x, *goal_y;        // targets stay fp64 like the reference's Python floats
+    const double *goal2_x, *goal2_y;
+    float* reward;
+    float *orient_x, *orient_y;  // unit vector pos -> goal of the CURRENT state (frame of the observation)
+    int *agent_done, *arrive_step, *regoal_count;
+    int *nb_count, *nb_idx, *obst_count, *obst_idx;
+    int *step_count, *arena_done, *episode;
+    unsigned long long* arena_stats;  // [A][8]
+    const ObstDev* obst;
+    const float* actions;  // null: orca_step
+    const float* reset_px; // explicit reset positions (reset kernel only)
+    const float* reset_py;
+    const int* reset_mask; // [A] reset only the arenas with a non-zero entry (reset kernels only; null = all)
+    unsigned long long* dbg;  // CA_STAMPS diagnostic build only: [waves][16] phase cycle counts
+    double reward_scale;
+    uint64_t seed;
+    int64_t arena_offset;
+    int n_obst, A, N, P, logP, K, S;
+    int a0, a1;  // this launch covers arenas [a0, a1) (chunked launches on several streams)
+    uint32_t flags;
+    float time_step, neighbor_dist, time_horizon, time_horizon_obst, radius, max_speed;
+    int max_step, done_mode;
+    float done_x_thresh;
+    float spawn_x0, spawn_x1, spawn_y0, spawn_y1, goal_x0, goal_x1, goal_y0, goal_y1;
+};
+
+enum { ST_EPISODES = 0, ST_COLL = 1, ST_OBST_COLL = 2, ST_GOALS = 3, ST_OVERFLOW = 4, ST_SUMREW = 5, ST_FROZEN = 6, ST_LASTEP = 7, ST_STRIDE = 8 };
+
+// CA_F_FREEZE: arenas whose arena_done flag is set are left exactly as they are
+__device__ __forceinline__ bool arena_frozen(const StepArgs& p, int a) {
+    return (p.flags & 16u) != 0 && a < p.a1 && p.arena_done[a] != 0;
+}
+
+// Orders the LDS traffic of ONE wave: LDS executes a wave's instructions in issue order, so lanes of
+// the same wave only need the compiler not to move accesses across this point and the earlier
+// operations to have been issued and returned (s_waitcnt lgkmcnt(0)).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ ObstDev load_obst(const ObstDev* __restrict__ t, int i) {
+    const int4* q = reinterpret_cast<const int4*>(t + i);
+    const int4 a = q[0], b = q[1], c = q[2], d = q[3];
+    ObstDev o;
+    o.px = __int_as_float(a.x); o.py = __int_as_float(a.y); o.ux = __int_as_float(a.z); o.uy = __int_as_float(a.w);
+    o.qx = __int_as_float(b.x); o.qy = __int_as_float(b.y); o.qux = __int_as_float(b.z); o.quy = __int_as_float(b.w);
+    o.pux = __int_as_float(c.x); o.puy = __int_as_float(c.y); o.next = c.z; o.prev = c.w;
+    o.convex = d.x; o.qconvex = d.y; o.pad0 = 0; o.pad1 = 0;
+    return o;
+}
+
+#ifdef CA_STAMPS  // diagnostic build: per-wave cycle count of each phase (never in the product library)
+#if CA_STAMPS == 2   // wall-clock variant: the 100 MHz device-wide counter (wave timelines across CUs)
+#define CA_STAMP_CLOCK() __builtin_amdgcn_s_memrealtime()
+#else                // per-CU shader-clock counter (phase shares inside a wave)
+#define CA_STAMP_CLOCK() __builtin_amdgcn_s_memtime()
+#endif
+#define CA_STAMP(k)                                                                      \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        const unsigned long long _t = CA_STAMP_CLOCK();                                  \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                              \
+        if ((threadIdx.x & 63) == 0 && p.dbg)                                            \
+            p.dbg[((size_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6)) * 16 + (k)] = _t; \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define CA_STAMP(k) do { } while (0)
+#endif
+
+}  // namespace ca

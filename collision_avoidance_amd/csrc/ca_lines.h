@@ -1,0 +1,159 @@
+// ca_lines.h -- ORCA half-planes of agent neighbours (App. A.4) and obstacle edges (App. A.3)
+// Part of the HIP kernels of libcaenv.so (see ca_kernels.h for the overview and the numerics contract).
+#pragma once
+#include "ca_common.h"
+
+namespace ca {
+
+// App. A.4: the half-plane induced by one neighbouring agent (both agents have radius R)
+__device__ __forceinline__ Line agent_orca_line(V2 pos, V2 vel, V2 opos, V2 ovel, float R, float invT, float invDt) {
+    const V2 rp = opos - pos;
+    const V2 rv = vel - ovel;
+    const float distSq = absSq(rp);
+    const float cr = R + R;
+    const float crSq = sqr(cr);
+    Line line;
+    V2 u;
+    if (distSq > crSq) {
+        const V2 w = rv - invT * rp;
+        const float wLenSq = absSq(w);
+        const float dp1 = dot(w, rp);
+        if (dp1 < 0.0f && sqr(dp1) > crSq * wLenSq) {
+            const float wLen = sqrtf(wLenSq);
+            const V2 unitW = vdiv(w, wLen);
+            line.dir = mk(unitW.y, -unitW.x);
+            u = (cr * invT - wLen) * unitW;
+        } else {
+            const float leg = sqrtf(distSq - crSq);
+            if (det(rp, w) > 0.0f)
+                line.dir = vdiv(mk(rp.x * leg - rp.y * cr, rp.x * cr + rp.y * leg), distSq);
+            else
+                line.dir = -vdiv(mk(rp.x * leg + rp.y * cr, -rp.x * cr + rp.y * leg), distSq);
+            const float dp2 = dot(rv, line.dir);
+            u = dp2 * line.dir - rv;
+        }
+    } else {
+        const V2 w = rv - invDt * rp;
+        const float wLen = vabs(w);
+        const V2 unitW = vdiv(w, wLen);
+        line.dir = mk(unitW.y, -unitW.x);
+        u = (cr * invDt - wLen) * unitW;
+    }
+    line.point = vel + 0.5f * u;
+    return line;
+}
+
+// App. A.3: the half-plane induced by the obstacle edge e.  Returns false when the edge yields no
+// line (already covered, non-convex vertex, foreign leg).  "o1"/"o2" are the edge's two vertices;
+// the oblique cases collapse the edge onto one of them, exactly as the contract's o2<-o1 / o1<-o2.
+// `covered(a, b)`: true when some earlier obstacle line already excludes both scaled end points.
+template <class CoveredFn>
+__device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, int e, V2 pos, V2 vel, float R,
+                                               float invTO, CoveredFn covered, Line& line) {
+    const ObstDev E = load_obst(tab, e);
+    V2 o1p = mk(E.px, E.py), o2p = mk(E.qx, E.qy);
+    V2 o1u = mk(E.ux, E.uy), o2u = mk(E.qux, E.quy);
+    V2 lnu = mk(E.pux, E.puy);  // unitDir of o1's left neighbour (its prev vertex)
+    bool o1c = E.convex != 0, o2c = E.qconvex != 0;
+    bool same = false;
+    const V2 rp1 = o1p - pos;
+    const V2 rp2 = o2p - pos;
+    if (covered(invTO * rp1, invTO * rp2)) return false;
+    const float distSq1 = absSq(rp1), distSq2 = absSq(rp2), radiusSq = sqr(R);
+    const V2 ov = o2p - o1p;
+    const float s = dot(-rp1, ov) / absSq(ov);
+    const float distSqLine = absSq(-rp1 - s * ov);
+    if (s < 0.0f && distSq1 <= radiusSq) {
+        if (o1c) {
+            line.point = mk(0.0f, 0.0f);
+            line.dir = normalize(mk(-rp1.y, rp1.x));
+            return true;
+        }
+        return false;
+    } else if (s > 1.0f && distSq2 <= radiusSq) {
+        if (o2c && det(rp2, o2u) >= 0.0f) {
+            line.point = mk(0.0f, 0.0f);
+            line.dir = normalize(mk(-rp2.y, rp2.x));
+            return true;
+        }
+        return false;
+    } else if (s >= 0.0f && s < 1.0f && distSqLine <= radiusSq) {
+        line.point = mk(0.0f, 0.0f);
+        line.dir = -o1u;
+        return true;
+    }
+    V2 leftLeg, rightLeg;
+    if (s < 0.0f && distSqLine <= radiusSq) {
+        if (!o1c) return false;
+        o2p = o1p; o2u = o1u; o2c = o1c; same = true;  // o2 <- o1
+        const float leg1 = sqrtf(distSq1 - radiusSq);
+        leftLeg = vdiv(mk(rp1.x * leg1 - rp1.y * R, rp1.x * R + rp1.y * leg1), distSq1);
+        rightLeg = vdiv(mk(rp1.x * leg1 + rp1.y * R, -rp1.x * R + rp1.y * leg1), distSq1);
+    } else if (s > 1.0f && distSqLine <= radiusSq) {
+        if (!o2c) return false;
+        lnu = o1u;                                     // the new o1's prev vertex is the old o1
+        o1p = o2p; o1u = o2u; o1c = o2c; same = true;  // o1 <- o2
+        const float leg2 = sqrtf(distSq2 - radiusSq);
+        leftLeg = vdiv(mk(rp2.x * leg2 - rp2.y * R, rp2.x * R + rp2.y * leg2), distSq2);
+        rightLeg = vdiv(mk(rp2.x * leg2 + rp2.y * R, -rp2.x * R + rp2.y * leg2), distSq2);
+    } else {
+        if (o1c) {
+            const float leg1 = sqrtf(distSq1 - radiusSq);
+            leftLeg = vdiv(mk(rp1.x * leg1 - rp1.y * R, rp1.x * R + rp1.y * leg1), distSq1);
+        } else {
+            leftLeg = -o1u;
+        }
+        if (o2c) {
+            const float leg2 = sqrtf(distSq2 - radiusSq);
+            rightLeg = vdiv(mk(rp2.x * leg2 + rp2.y * R, -rp2.x * R + rp2.y * leg2), distSq2);
+        } else {
+            rightLeg = o1u;
+        }
+    }
+    bool leftForeign = false, rightForeign = false;
+    if (o1c && det(leftLeg, -lnu) >= 0.0f) {
+        leftLeg = -lnu;
+        leftForeign = true;
+    }
+    if (o2c && det(rightLeg, o2u) <= 0.0f) {
+        rightLeg = o2u;
+        rightForeign = true;
+    }
+    const V2 leftCut = invTO * (o1p - pos);
+    const V2 rightCut = invTO * (o2p - pos);
+    const V2 cutVec = rightCut - leftCut;
+    const float t = same ? 0.5f : dot(vel - leftCut, cutVec) / absSq(cutVec);
+    const float tLeft = dot(vel - leftCut, leftLeg);
+    const float tRight = dot(vel - rightCut, rightLeg);
+    if ((t < 0.0f && tLeft < 0.0f) || (same && tLeft < 0.0f && tRight < 0.0f)) {
+        const V2 unitW = normalize(vel - leftCut);
+        line.dir = mk(unitW.y, -unitW.x);
+        line.point = leftCut + R * invTO * unitW;
+        return true;
+    } else if (t > 1.0f && tRight < 0.0f) {
+        const V2 unitW = normalize(vel - rightCut);
+        line.dir = mk(unitW.y, -unitW.x);
+        line.point = rightCut + R * invTO * unitW;
+        return true;
+    }
+    const float INF = __int_as_float(0x7f800000);
+    const float dCut = (t < 0.0f || t > 1.0f || same) ? INF : absSq(vel - (leftCut + t * cutVec));
+    const float dLeft = (tLeft < 0.0f) ? INF : absSq(vel - (leftCut + tLeft * leftLeg));
+    const float dRight = (tRight < 0.0f) ? INF : absSq(vel - (rightCut + tRight * rightLeg));
+    if (dCut <= dLeft && dCut <= dRight) {
+        line.dir = -o1u;
+        line.point = leftCut + R * invTO * mk(-line.dir.y, line.dir.x);
+        return true;
+    } else if (dLeft <= dRight) {
+        if (leftForeign) return false;
+        line.dir = leftLeg;
+        line.point = leftCut + R * invTO * mk(-line.dir.y, line.dir.x);
+        return true;
+    }
+    if (rightForeign) return false;
+    line.dir = -rightLeg;
+    line.point = rightCut + R * invTO * mk(-line.dir.y, line.dir.x);
+    return true;
+}
+
+}  // namespace ca

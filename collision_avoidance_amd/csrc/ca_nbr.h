@@ -1,0 +1,214 @@
+// ca_nbr.h -- neighbour search (App. A.2): sorted key lists, brute-force and uniform-grid scans
+// Part of the HIP kernels of libcaenv.so (see ca_kernels.h for the overview and the numerics contract).
+#pragma once
+#include "ca_common.h"
+
+namespace ca {
+
+// Sorted insertion into a register-resident list kept ascending, the last entry falling off.
+// An entry is the 64-bit key (distance bits << 32 | index) held in a double register pair: for
+// non-negative floats the bit pattern is monotone, so key order IS the (distance, index) order of the
+// contract (App. A.2: ascending distance, ties to the lower index), and as positive, never-NaN doubles
+// the keys are ordered by v_min_f64 / v_max_f64.  Insertion is then, for every slot independently and
+// in place,   new[k] = max(old[k-1], min(old[k], x))   -- two VALU instructions per slot, no compare
+// masks, no register copies.  (Inline asm because the compiler would add a canonicalising
+// v_max_f64 v,v,v per operand; keys are never NaN so nothing needs quieting.)
+// A list shorter than the array is stored RIGHT-ALIGNED behind dummy -inf slots (which never move):
+// its largest key is then always the last element, a compile-time index.
+__device__ __forceinline__ double key_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double key_max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double make_key(float d, int idx) {
+    return __longlong_as_double((long long)(((unsigned long long)__float_as_uint(d) << 32) | (unsigned)idx));
+}
+__device__ __forceinline__ float key_dist(double k) { return __uint_as_float((unsigned)((unsigned long long)__double_as_longlong(k) >> 32)); }
+__device__ __forceinline__ int key_index(double k) { return (int)(unsigned)(unsigned long long)__double_as_longlong(k); }
+template <int MAXN>
+__device__ __forceinline__ void sorted_insert(double (&key)[MAXN], double x) {
+#pragma unroll
+    for (int k = MAXN - 1; k >= 1; --k) key[k] = key_max(key[k - 1], key_min(key[k], x));
+    key[0] = key_min(key[0], x);
+}
+
+// ============================================================================================
+// Neighbour search for every agent (App. A.2): the obstacle edges within range and
+// the K nearest agents, written as the lists [A,S,N] / [A,K,N] that the solve kernel and the
+// observation read.  A kernel of its own because it needs almost no LDS (the arena's positions,
+// 8 B per lane): it runs at full occupancy and is issue-bound, whereas the solve kernel is tied to
+// its 16 B x (K+S) line table per lane.
+// ============================================================================================
+template <int KMAX, int BS>
+__device__ __forceinline__ void nbr_body(const StepArgs& p) {
+#ifndef CA_NBR_NO_VGPR_PAD
+    // Claim 128 VGPRs (the kernel needs 56): at most 4 waves then fit on a SIMD, so a launch that brings one
+    // wave per SIMD slot (4096 x 64 lanes on 256 CUs) is spread evenly.  Without it the dispatcher puts
+    // anything from 1 to 7 of these light waves on a SIMD and the kernel waits for the fullest one.
+    asm volatile("" ::: "v127");
+#endif
+    __shared__ float s_px[BS];
+    __shared__ float s_py[BS];
+    const int tid = threadIdx.x;
+    const int P = p.P;
+    const int la = tid >> p.logP;
+    const int i = tid & (P - 1);
+    const int apb = BS >> p.logP;
+    const int a = p.a0 + blockIdx.x * apb + la;
+    const bool active = (a < p.a1) && (i < p.N) && !arena_frozen(p, a);
+    const int N = p.N, K = p.K, S = p.S;
+    const int q = active ? a * N + i : 0;
+    const int lbase = la << p.logP;
+    CA_STAMP(12);
+    V2 pos = mk(0.0f, 0.0f);
+    if (active) pos = mk(p.pos_x[q], p.pos_y[q]);
+    s_px[tid] = pos.x; s_py[tid] = pos.y;
+    __syncthreads();
+
+    const float INF = __int_as_float(0x7f800000);
+    // ---- obstacle neighbours (App. A.2): brute force over the edge table ----
+    const int sofs = SMAX - S;  // the S-entry list is right-aligned in the register array
+    const double KEY_EMPTY = __longlong_as_double(0x7F800000FFFFFFFFll);  // (+inf, -1)
+    const double KEY_DUMMY = __longlong_as_double((long long)0xFFF0000000000000ull);  // -inf: never moves
+    double okey[SMAX];
+#pragma unroll
+    for (int k = 0; k < SMAX; ++k) okey[k] = (k < sofs) ? KEY_DUMMY : KEY_EMPTY;
+    int oin = 0;
+    {
+        const float rangeSq = sqr(p.time_horizon_obst * p.max_speed + p.radius);
+        for (int e = 0; e < p.n_obst; ++e) {
+            const ObstDev o1 = p.obst[e];
+            const V2 a1 = mk(o1.px, o1.py), a2 = mk(o1.qx, o1.qy);
+            const float alol = leftOf(a1, a2, pos);
+            const float dsl = sqr(alol) / absSq(a2 - a1);
+            if (active && dsl < rangeSq && alol < 0.0f) {
+                const float dsq = distSqPointSegment(a1, a2, pos);
+                if (dsq < rangeSq) {
+                    ++oin;
+                    sorted_insert<SMAX>(okey, make_key(dsq, e));
+                }
+            }
+        }
+    }
+    const int ocnt = oin < S ? oin : S;
+    CA_STAMP(13);
+
+    // ---- agent neighbours (App. A.2): K nearest within neighbor_dist, ties -> lower index ----
+    const int kofs = KMAX - K;  // the K-entry list is right-aligned in the register array
+    double nkey[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) nkey[k] = (k < kofs) ? KEY_DUMMY : KEY_EMPTY;
+    int ncnt = 0;
+    bool scanned = false;
+    if constexpr (BS >= 256) {
+        // Large arenas (one arena per workgroup, >= 192 agents): a uniform grid with cells at least neighbor_dist
+        // wide, rebuilt in LDS every step (counting sort of the agent indices by cell), so that an agent scans
+        // the 3 x 3 cells around it -- three contiguous runs of the sorted list -- instead of the whole arena.
+        // The cells are visited in no particular index order, so a candidate enters on `distance <= current
+        // K-th distance` and the 64-bit (distance, index) keys settle ties; the list is the same K smallest
+        // keys within neighbor_dist that the index-order scan keeps.
+        if (P == BS && N >= 192 && K > 0) {
+            __shared__ unsigned s_box[4];          // ordered-uint images of min x, min y, max x, max y
+            __shared__ int s_ccnt[256];            // agents per cell
+            __shared__ int s_cstart[257];          // first position of a cell in s_sorted
+            __shared__ unsigned short s_sorted[BS];
+            auto ord = [](float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+            auto unord = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); };
+            if (tid < 2) s_box[tid] = 0xFFFFFFFFu;
+            if (tid >= 2 && tid < 4) s_box[tid] = 0u;
+            if (tid < 256) s_ccnt[tid] = 0;
+            __syncthreads();
+            const bool in_arena = (a < p.a1) && (i < N);  // frozen arenas skip the scan but keep the barriers
+            if (in_arena) {
+                atomicMin(&s_box[0], ord(pos.x)); atomicMin(&s_box[1], ord(pos.y));
+                atomicMax(&s_box[2], ord(pos.x)); atomicMax(&s_box[3], ord(pos.y));
+            }
+            __syncthreads();
+            const float x0 = unord(s_box[0]), y0 = unord(s_box[1]);
+            const float ex = unord(s_box[2]) - x0, ey = unord(s_box[3]) - y0;
+            const float cs = fmaxf(p.neighbor_dist, fmaxf(ex, ey) * (1.0f / 15.5f));  // at most 16 x 16 cells
+            const float ics = 1.0f / cs;
+            const int Gx = min(16, (int)(ex * ics) + 1), Gy = min(16, (int)(ey * ics) + 1);
+            const int cx = min(Gx - 1, max(0, (int)((pos.x - x0) * ics))), cy = min(Gy - 1, max(0, (int)((pos.y - y0) * ics)));
+            int rank = 0;
+            if (in_arena) rank = atomicAdd(&s_ccnt[cy * Gx + cx], 1);
+            __syncthreads();
+            if (tid < 64) {  // exclusive prefix sum over the (<= 256) cells: four cells per lane of the first wave
+                const int c0 = s_ccnt[4 * tid], c1 = s_ccnt[4 * tid + 1], c2 = s_ccnt[4 * tid + 2], c3 = s_ccnt[4 * tid + 3];
+                int incl = c0 + c1 + c2 + c3;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int t = __shfl_up(incl, off);
+                    if (tid >= off) incl += t;
+                }
+                const int b = incl - (c0 + c1 + c2 + c3);
+                s_cstart[4 * tid] = b; s_cstart[4 * tid + 1] = b + c0; s_cstart[4 * tid + 2] = b + c0 + c1;
+                s_cstart[4 * tid + 3] = b + c0 + c1 + c2;
+                if (tid == 63) s_cstart[256] = incl;
+            }
+            __syncthreads();
+            if (in_arena) s_sorted[s_cstart[cy * Gx + cx] + rank] = (unsigned short)i;
+            __syncthreads();
+            const float rangeSq0 = sqr(p.neighbor_dist);
+            float rangeK = rangeSq0;  // distance of the current K-th entry once the list is full
+            for (int ry = -1; ry <= 1; ++ry) {
+                const int row = cy + ry;
+                int lo = 0, hi = 0;
+                if (active && row >= 0 && row < Gy) {
+                    lo = s_cstart[row * Gx + max(cx - 1, 0)];
+                    hi = s_cstart[row * Gx + min(cx + 1, Gx - 1) + 1];
+                }
+                for (int t = lo; t < hi; ++t) {
+                    const int j = s_sorted[t];
+                    const float dsq = absSq(pos - mk(s_px[j], s_py[j]));
+                    if (j != i && dsq < rangeSq0 && dsq <= rangeK) {
+                        sorted_insert<KMAX>(nkey, make_key(dsq, j));
+                        if (ncnt < K) ++ncnt;
+                        if (ncnt == K) rangeK = key_dist(nkey[KMAX - 1]);
+                    }
+                }
+            }
+            scanned = true;
+        }
+    }
+    if (K > 0 && !scanned) {
+        float rangeSq = sqr(p.neighbor_dist);
+        V2 o_next = mk(s_px[lbase], s_py[lbase]);
+        for (int j = 0; j < N; ++j) {
+            const V2 o = o_next;  // the next candidate's position is in flight while this one is inserted
+            if (j + 1 < N) o_next = mk(s_px[lbase + j + 1], s_py[lbase + j + 1]);
+            const float dsq = absSq(pos - o);
+            if (active && j != i && dsq < rangeSq) {
+                sorted_insert<KMAX>(nkey, make_key(dsq, j));
+                if (ncnt < K) ++ncnt;
+                if (ncnt == K) rangeSq = key_dist(nkey[KMAX - 1]);
+            }
+        }
+    }
+
+    CA_STAMP(14);
+    if (active) {
+        if (oin > S) atomicAdd(reinterpret_cast<int*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_OVERFLOW]), 1);
+        p.nb_count[q] = ncnt;
+        p.obst_count[q] = ocnt;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k >= kofs) p.nb_idx[((size_t)a * K + (k - kofs)) * N + i] = key_index(nkey[k]);
+#pragma unroll
+        for (int k = 0; k < SMAX; ++k)
+            if (k >= sofs) p.obst_idx[((size_t)a * S + (k - sofs)) * N + i] = key_index(okey[k]);
+    }
+    CA_STAMP(15);
+}
+
+template <int KMAX, int BS>
+__global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
+    nbr_body<KMAX, BS>(p);
+}
+
+}  // namespace ca

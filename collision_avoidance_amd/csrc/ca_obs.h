@@ -1,0 +1,381 @@
+// ca_obs.h -- the laser observation kernel
+// Part of the HIP kernels of libcaenv.so (see ca_kernels.h for the overview and the numerics contract).
+#pragma once
+#include "ca_common.h"
+
+namespace ca {
+
+// ============================================================================================
+// Laser observation (env.py:231-318, utils.py:5-113).
+//
+// A workgroup (256 lanes) owns 16 agents of ONE arena; 16 lanes per agent.  The arena's
+// positions/velocities are staged in LDS once (the neighbour gathers then never leave the CU).
+// Phase A -- lane per (source, ray) pair: the 16 lanes of an agent walk the pairs (8 octagon chords
+//   per ORCA agent neighbour, one segment per ORCA obstacle neighbour), rotate each segment into
+//   the goal-aligned frame and test it only against the rays that can possibly reach it: the
+//   rays inside the segment's angular span as seen from the origin (a conservative superset, see
+//   ray_span).  The ray/segment test itself is the reference's arithmetic, so culling never
+//   changes a result.  A hit is merged into the ray's slot with one LDS ds_min_u64 on the key
+//   (distance bits << 32 | segment index): the minimum distance wins and equal distances resolve
+//   to the first segment, exactly like a serial first-minimum scan.
+// Phase B -- lane per RAY: re-derives the winning segment's hit point and velocity and writes its
+//   4 floats; the 16 lanes of an agent write its 256-B row, a wave stores 1 KiB contiguously.
+// ============================================================================================
+struct ObsArgs {
+    const float *pos_x, *pos_y, *vel_x, *vel_y, *orient_x, *orient_y;
+    const int *nb_count, *nb_idx, *obst_count, *obst_idx;
+    const ObstDev* obst;
+    float* obs;
+    int A, N, K, S, bpa;  // bpa = workgroups per arena = ceil(N / 16)
+    int a0;               // first arena of this launch
+    unsigned long long* dbg;  // CA_STAMPS diagnostic build only: [waves][16] phase time stamps
+    float radius;         // of the octagon = agent radius (env.py:31,338)
+    float rays[32];       // env.py:321-332
+    float oct[32];        // env.py:335-350
+};
+
+#ifdef CA_STAMPS
+#define CA_OSTAMP(k)                                                                       \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        const unsigned long long _t = CA_STAMP_CLOCK();                                    \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                \
+        if ((threadIdx.x & 63) == 0 && p.dbg)                                              \
+            p.dbg[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (k)] = _t; \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+#else
+#define CA_OSTAMP(k) do { } while (0)
+#endif
+// The observation workgroup: OBS_BS lanes = OBS_BS/16 agents of ONE arena (template parameter: 256,
+// 512 or 1024 lanes, so that a workgroup can own a whole arena of up to 64 agents and stage it once).
+constexpr int OBS_PAIRCAP = 16 * (16 + 8);  // (source, ray) pairs of one agent: <= 16 rays x (K + S) sources
+
+// LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | hit points [16][16] float2 | agent frames [16] float4 | nb idx [16][16] | obstacle idx [16][8]
+//              | ray and octagon tables [64] | pair counts [2][16] | (source, ray) pair lists [16][384] u16
+//              (a list holds the agent-neighbour pairs from its front and the obstacle pairs from its back)
+__host__ __device__ inline size_t obs_lds_bytes(int N, int obs_bs) {
+    const size_t apb = obs_bs / 16;
+    return (size_t)N * 16 + 2 * apb * 16 * 8 + apb * 16 + apb * 16 * 4 + apb * 8 * 4 + 64 * 4 + 2 * apb * 4 + apb * OBS_PAIRCAP * 2;
+}
+#ifndef CA_OBS_BS_MAX
+#define CA_OBS_BS_MAX 256
+#endif
+// 256 lanes measured best (C3: 99 us; 512 lanes: see profiles/r01_k_obs_variants.txt; 1024 lanes: 127 us)
+__host__ __device__ inline int obs_block_threads(int N) {
+    const int want = N > 32 ? 1024 : (N > 16 ? 512 : 256);
+    return want < CA_OBS_BS_MAX ? want : CA_OBS_BS_MAX;
+}
+
+struct SegGeom {  // one segment in the goal-aligned frame, in the reference's intermediate terms
+    float s02x, s02y;  // utils.py:19-20  p0 - p2, p0 = (0,0)
+    float s32x, s32y;  // utils.py:11-12  p3 - p2
+    float t_numer;     // utils.py:26
+    float r1x, r1y, r2x, r2y;
+};
+
+// position of a point on the "ray dial": ray i points along (cos(i d), -sin(i d)), d = 2pi/16;
+// returns u in [0,16) with |error| < 1e-4.  Only used to pick candidate rays (never for results).
+__device__ __forceinline__ float ray_dial(float x, float y) {
+    const float yy = -y;
+    const float ax = fabsf(x), ay = fabsf(yy);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mn * __builtin_amdgcn_rcpf(mx);
+    const float s = a * a;
+    float r = a * (0.99997726f + s * (-0.33262347f + s * (0.19354346f + s * (-0.11643287f +
+              s * (0.05265332f + s * -0.01172120f)))));
+    r = (ay > ax) ? 1.57079632679f - r : r;
+    r = (x < 0.0f) ? 3.14159265359f - r : r;
+    r = (yy < 0.0f) ? -r : r;
+    const float u = r * 2.54647908947f;  // 16 / (2 pi)
+    return (u < 0.0f) ? u + 16.0f : u;
+}
+
+// Ray windows.  For a SEGMENT with end points p2, p3 every ray the exact test could accept lies in
+// the angular span between the directions of p2 and p3 (short way round): the test accepts a ray
+// only if its direction is between them up to fp32 rounding of two cross products, i.e. up to
+// ~1e-7 rad unless an end point is very close to the origin compared with the other; the dial error
+// is < 1e-4 and the margin is 0.01 dial units (3.9e-3 rad).  Segments passing (almost) through the
+// origin, where "short way round" is ill-defined, get all 16 rays.  For an agent NEIGHBOUR the
+// window is that of the circle through its octagon's vertices (see the pre-pass).
+template <int OBS_BS>
+__global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
+    constexpr int OBS_APB = OBS_BS / 16;  // agents per workgroup
+    extern __shared__ float4 smem4[];
+    const int tid = threadIdx.x;
+    const int g = tid >> 4, r = tid & 15;
+    const int N = p.N, K = p.K, S = p.S;
+    const int ab = blockIdx.x / p.bpa;
+    const int a = p.a0 + ab;
+    const int i = (blockIdx.x - ab * p.bpa) * OBS_APB + g;
+    const bool active = i < N;
+    const size_t q = (size_t)a * N + (active ? i : 0);
+
+    float* s_px = reinterpret_cast<float*>(smem4);
+    float* s_py = s_px + N;
+    float* s_vx = s_py + N;
+    float* s_vy = s_vx + N;
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_vy + N);  // N*16 B: 8-aligned
+    float2* s_hit = reinterpret_cast<float2*>(s_key + OBS_APB * 16);             // hit point of the key's chord
+    float4* s_frame = reinterpret_cast<float4*>(s_hit + OBS_APB * 16);           // (cos, sin, pos x, pos y) per agent
+    int* s_nb = reinterpret_cast<int*>(s_frame + OBS_APB);
+    int* s_ob = s_nb + OBS_APB * 16;
+    float* s_rays = reinterpret_cast<float*>(s_ob + OBS_APB * 8);  // [32] rays then [32] octagon
+    float* s_oct = s_rays + 32;
+    int* s_cnt = reinterpret_cast<int*>(s_oct + 32);                       // [16] neighbour pairs per agent
+    int* s_cnt2 = s_cnt + OBS_APB;                                         // [16] obstacle pairs per agent
+    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_cnt2 + OBS_APB);  // [16][OBS_PAIRCAP]
+    CA_OSTAMP(0);
+    if (tid < 32) { s_rays[tid] = p.rays[tid]; s_oct[tid] = p.oct[tid]; }
+
+    for (int t = tid; t < N; t += OBS_BS) {
+        const size_t qa = (size_t)a * N + t;
+        s_px[t] = p.pos_x[qa]; s_py[t] = p.pos_y[qa]; s_vx[t] = p.vel_x[qa]; s_vy[t] = p.vel_y[qa];
+    }
+    int nn = 0, ns = 0;
+    float c = 1.0f, s = 0.0f;
+    if (active) {
+        nn = p.nb_count[q]; ns = p.obst_count[q];
+        c = p.orient_x[q]; s = -p.orient_y[q];  // utils.py:48-51: cos/sin of -atan2(orientation)
+        if (r < nn) s_nb[g * 16 + r] = p.nb_idx[((size_t)a * K + r) * N + i];
+        if (r < ns) s_ob[g * 8 + r] = p.obst_idx[((size_t)a * S + r) * N + i];
+    }
+    s_key[g * 16 + r] = ~0ull;
+    if (r == 0) { s_cnt[g] = 0; s_cnt2[g] = 0; }
+    CA_OSTAMP(1);
+    __syncthreads();
+    CA_OSTAMP(2);
+
+    const int M = 8 * nn + ns;
+    float mx = 0.0f, my = 0.0f;
+    if (M > 0) { mx = s_px[i]; my = s_py[i]; }
+    if (r == 0) s_frame[g] = make_float4(c, s, mx, my);  // phase A lanes also work for the wave's other agents
+    // ---- pre-pass: which (source, ray) pairs are worth the exact test?  Supersets only; never results. ----
+    // (1) lane per agent NEIGHBOUR: all 8 octagon vertices lie on the circle of radius R around it, so the
+    // rays within asin(R/d) of its direction are a superset for each of its 8 chords.  asin(t) <= t + (pi/2 - 1) t^3
+    // on [0, 1] ((asin t - t) / t^3 grows from 1/6 to pi/2 - 1); margin 0.02 dial units = 7.8e-3 rad covers the
+    // dial's 1e-4 and the approximate reciprocal square root.
+    for (int k = r; k < nn; k += 16) {
+        const int nb = s_nb[g * 16 + k];
+        const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
+        const float d2 = rx * rx + ry * ry, R = p.radius;
+        const float ax = c * rx - s * ry, ay = s * rx + c * ry;
+        const bool all = !(d2 > 1.0404f * R * R);  // the agent is inside (or within 2 % of) that circle
+        const float ua = ray_dial(ax, ay);
+        const float t = R * __builtin_amdgcn_rsqf(d2);
+        const float hw = t * (1.0f + 0.5708f * (t * t)) * 2.54647908947f + 0.02f;
+        int i0 = (int)ceilf(ua - hw), i1 = (int)floorf(ua + hw);
+        if (all || i1 - i0 >= 15) { i0 = 0; i1 = 15; }
+        const int w = i1 - i0 + 1;
+        if (w > 0) {  // neighbour pairs fill the list from the front (list order is irrelevant: commutative minimum)
+            const int base = atomicAdd(&s_cnt[g], w);
+            for (int t2 = 0; t2 < w; ++t2)
+                s_pair[g * OBS_PAIRCAP + base + t2] = (unsigned short)((k << 4) | ((i0 + t2) & 15));
+        }
+    }
+    // (2) lane per RAY, one obstacle edge at a time: the exact test can accept a ray only if the ray's line
+    // separates the edge's end points and the crossing is not behind the origin, i.e. (up to rounding, covered
+    // by tolE = 50x the error of these products) the two end points are not on the same side of the line and
+    // not both behind.  Obstacle pairs fill the agent's list from the back.
+    {
+        const float dx = s_rays[2 * r], dy = s_rays[2 * r + 1];
+        int cnt2 = 0;
+        for (int sidx = 0; sidx < ns; ++sidx) {
+            const ObstDev o1 = load_obst(p.obst, s_ob[g * 8 + sidx]);
+            const float x1 = o1.px - mx, y1 = o1.py - my, x2 = o1.qx - mx, y2 = o1.qy - my;
+            const float ax = c * x1 - s * y1, ay = s * x1 + c * y1;
+            const float bx = c * x2 - s * y2, by = s * x2 + c * y2;
+            const float c2 = dx * ay - dy * ax, c3 = dx * by - dy * bx;
+            const float f2 = dx * ax + dy * ay, f3 = dx * bx + dy * by;
+            const float tolE = 1e-5f * p.rays[0] * (fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by) + 1.0f);
+            const bool keep = !(c2 > tolE && c3 > tolE) && !(c2 < -tolE && c3 < -tolE) && (fmaxf(f2, f3) >= -tolE);
+            const unsigned grp = (unsigned)(__ballot(keep) >> (threadIdx.x & 48)) & 0xFFFFu;  // my agent's 16 lanes
+            if (keep)
+                s_pair[g * OBS_PAIRCAP + OBS_PAIRCAP - 1 - (cnt2 + __popc(grp & ((1u << r) - 1u)))] =
+                    (unsigned short)(((nn + sidx) << 4) | r);
+            cnt2 += __popc(grp);
+        }
+        if (r == 0) s_cnt2[g] = cnt2;
+    }
+    CA_OSTAMP(3);
+    wave_lds_sync();  // the 16 lanes of an agent are in one wave: no workgroup barrier needed
+    CA_OSTAMP(4);
+    // segment m of this agent in the rotated frame (env.py:283-294, 305-315; utils.py:55-62)
+    auto build = [&](int m, SegGeom& sg, float& velx, float& vely, bool want_vel) {
+        float x1, y1, x2, y2, vx = 0.0f, vy = 0.0f;
+        if (m < 8 * nn) {
+            const int k = m >> 3, e = m & 7;
+            const int nb = s_nb[g * 16 + k];
+            const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
+            const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
+            x1 = oc.x + rx; y1 = oc.y + ry;
+            x2 = oc.z + rx; y2 = oc.w + ry;
+            if (want_vel) { vx = s_vx[nb]; vy = s_vy[nb]; }  // env.py:252
+        } else {
+            const ObstDev o1 = load_obst(p.obst, s_ob[g * 8 + (m - 8 * nn)]);
+            x1 = o1.px - mx; y1 = o1.py - my;
+            x2 = o1.qx - mx; y2 = o1.qy - my;
+        }
+        sg.r1x = c * x1 - s * y1; sg.r1y = s * x1 + c * y1;  // utils.py:59
+        sg.r2x = c * x2 - s * y2; sg.r2y = s * x2 + c * y2;  // utils.py:60
+        sg.s32x = sg.r2x - sg.r1x; sg.s32y = sg.r2y - sg.r1y;
+        sg.s02x = 0.0f - sg.r1x; sg.s02y = 0.0f - sg.r1y;
+        sg.t_numer = sg.s32x * sg.s02y - sg.s32y * sg.s02x;
+        if (want_vel) {
+            const float lvx = x1 + vx, lvy = y1 + vy;                      // utils.py:57
+            const float rvx = c * lvx - s * lvy, rvy = s * lvx + c * lvy;  // utils.py:61
+            velx = rvx - sg.r1x; vely = rvy - sg.r1y;                      // utils.py:62
+        }
+    };
+    // chord e of neighbour slot k of agent ga (one of this wave's four), in ga's frame fr = (cos, sin, x, y)
+    auto build_nb = [&](int ga, const float4& fr, int k, int e, SegGeom& sg) {
+        const int nb = s_nb[ga * 16 + k];
+        const float rx = s_px[nb] - fr.z, ry = s_py[nb] - fr.w;
+        const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
+        const float x1 = oc.x + rx, y1 = oc.y + ry, x2 = oc.z + rx, y2 = oc.w + ry;
+        sg.r1x = fr.x * x1 - fr.y * y1; sg.r1y = fr.y * x1 + fr.x * y1;  // utils.py:59
+        sg.r2x = fr.x * x2 - fr.y * y2; sg.r2y = fr.y * x2 + fr.x * y2;  // utils.py:60
+        sg.s32x = sg.r2x - sg.r1x; sg.s32y = sg.r2y - sg.r1y;
+        sg.s02x = 0.0f - sg.r1x; sg.s02y = 0.0f - sg.r1y;
+        sg.t_numer = sg.s32x * sg.s02y - sg.s32y * sg.s02x;
+    };
+    // utils.py:5-40 for the ray with end point (s10x, s10y) starting at the origin.  (Deferring the
+    // division/sqrt/atomic of accepted pairs to a second loop over a hit bitmask, and a branch-free
+    // accept test, were both measured SLOWER: 136-138 us vs 117 us at C3.)
+    auto hit = [&](const SegGeom& sg, float s10x, float s10y, float& d, float& hx, float& hy) -> bool {
+        const float denom = s10x * sg.s32y - sg.s32x * s10y;          // utils.py:14
+        if (denom == 0.0f) return false;
+        const bool dpos = denom > 0.0f;
+        const float s_numer = s10x * sg.s02y - s10y * sg.s02x;        // utils.py:21
+        if ((s_numer < 0.0f) == dpos) return false;
+        if ((sg.t_numer < 0.0f) == dpos) return false;
+        if (((s_numer > denom) == dpos) || ((sg.t_numer > denom) == dpos)) return false;
+        const float t = sg.t_numer / denom;                            // utils.py:34
+        hx = 0.0f + t * s10x; hy = 0.0f + t * s10y;                    // utils.py:36-37
+        d = sqrtf(hx * hx + hy * hy);                                  // utils.py:38
+        return true;
+    };
+
+    // the same test and distance without early exits (the division of a rejected chord is computed and dropped)
+    auto hit_nb = [&](const SegGeom& sg, float s10x, float s10y, float& d, float& hx, float& hy) -> bool {
+        const float denom = s10x * sg.s32y - sg.s32x * s10y;          // utils.py:14
+        const float s_numer = s10x * sg.s02y - s10y * sg.s02x;        // utils.py:21
+        const bool dpos = denom > 0.0f;
+        const bool ok = (denom != 0.0f) && ((s_numer < 0.0f) != dpos) && ((sg.t_numer < 0.0f) != dpos) &&
+                        ((s_numer > denom) != dpos) && ((sg.t_numer > denom) != dpos);  // utils.py:15-31
+        const float t = sg.t_numer / denom;                            // utils.py:34
+        hx = 0.0f + t * s10x; hy = 0.0f + t * s10y;                    // utils.py:36-37
+        d = sqrtf(hx * hx + hy * hy);                                  // utils.py:38
+        return ok;
+    };
+
+    // ---- phase A: lane per (source, ray) pair ----
+    // An agent neighbour contributes the 8 chords of its octagon; consecutive chords share an end point
+    // bit for bit (env.py:335-350 builds them as a chain), so the 8 rotated vertices are computed once
+    // per pair and every chord is accept-tested against the pair's single ray.  Only accepted chords
+    // (about two per pair) are re-derived through build()/hit() for the exact hit distance.
+    const float tol = 2e-5f * p.rays[0] * (p.rays[0] + 2.0f * p.radius + 1.0f);  // rays[0] = neighbor_dist (env.py:321-332)
+    // The lane whose key is the ray's minimum after this trip's atomics leaves its hit point next to the key
+    // (the LDS executes one wave's instructions in order, so the re-read sees every lane's atomic of the trip;
+    // a later, smaller key overwrites both).  Phase B then needs no second division / square root.
+    auto merge = [&](int ga, int ray, float best, int best_m, float bhx, float bhy) {
+        if (best_m >= 0) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)best_m;
+            atomicMin(&s_key[ga * 16 + ray], key);
+            if (s_key[ga * 16 + ray] == key) s_hit[ga * 16 + ray] = make_float2(bhx, bhy);
+        }
+    };
+    // (neighbour, ray) pairs and (obstacle edge, ray) pairs in loops of their own: a wave that mixes the two
+    // kinds in one pass pays for both code paths.  The neighbour pairs of the wave's FOUR agents form one
+    // work list shared by its 64 lanes (an agent has 13 pairs on average but often a few more than 16, which
+    // would cost its 16 lanes -- and with them the wave -- a second trip).
+    const int g0 = g & ~3;
+    const int n0 = s_cnt[g0], n1 = s_cnt[g0 + 1], n2 = s_cnt[g0 + 2], n3 = s_cnt[g0 + 3];
+    const int ntot = n0 + n1 + n2 + n3;
+    for (int pi = tid & 63; pi < ntot; pi += 64) {
+        int ga = g0, li = pi;
+        { const bool b = li >= n0; ga = b ? g0 + 1 : ga; li = b ? li - n0 : li;
+          const bool b1 = b && li >= n1; ga = b1 ? g0 + 2 : ga; li = b1 ? li - n1 : li;
+          const bool b2 = b1 && li >= n2; ga = b2 ? g0 + 3 : ga; li = b2 ? li - n2 : li; }
+        const float4 fr = s_frame[ga];
+        const int pr = s_pair[ga * OBS_PAIRCAP + li];
+        const int k = pr >> 4, ray = pr & 15;
+        const float s10x = s_rays[2 * ray] - 0.0f, s10y = s_rays[2 * ray + 1] - 0.0f;
+        float best = __int_as_float(0x7f800000), bhx = 0.0f, bhy = 0.0f;
+        int best_m = -1;
+        const int nb = s_nb[ga * 16 + k];
+        const float rx = s_px[nb] - fr.z, ry = s_py[nb] - fr.w;
+        // Which chords can the exact test accept?  It needs the crossing parameter along the chord,
+        // s_numer / denom (utils.py:21-31), inside [0, 1], i.e. the ray's LINE must separate the chord's end
+        // points: with cr[e] = ray x vertex e (= -s_numer of chord e), a chord whose two end points lie on the
+        // same side of the line by more than `tol` cannot be accepted.  The filter does not need the reference's
+        // rounding, so it takes the cross products in the WORLD frame, where the octagon's vertices are constants:
+        // ray_w x (oct_e + rel) with ray_w the ray turned back by the agent's frame -- no vertex is rotated here.
+        // `tol` is 100x the rounding error of either form.  The survivors -- the entry and the exit chord, a
+        // third one when the line grazes a vertex -- go through the reference's arithmetic below.
+        const float wx = fr.x * s10x + fr.y * s10y, wy = fr.x * s10y - fr.y * s10x;
+        const float wb = wx * ry - wy * rx;
+        float cr[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
+            cr[e] = (wx * oc.y - wy * oc.x) + wb;
+        }
+        unsigned acc = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ca = cr[e], cb = cr[(e + 1) & 7];
+            const bool same_side = (ca > tol && cb > tol) || (ca < -tol && cb < -tol);
+            acc |= same_side ? 0u : (1u << e);
+        }
+        // ascending chord index, strict '<': the first minimum wins.  Two surviving chords (entry and exit)
+        // are evaluated side by side in straight-line code, so that the two instruction streams can share
+        // packed fp32 instructions; the arithmetic of each is the reference's (utils.py:14-38).
+        while (acc) {
+            const int e1 = __ffs(acc) - 1;
+            acc &= acc - 1;
+            const bool two = acc != 0;
+            const int e2 = two ? __ffs(acc) - 1 : e1;
+            acc &= acc - 1;  // (0 & anything stays 0)
+            SegGeom g1, g2;
+            build_nb(ga, fr, k, e1, g1);
+            build_nb(ga, fr, k, e2, g2);
+            float d1, d2, h1x, h1y, h2x, h2y;
+            const bool ok1 = hit_nb(g1, s10x, s10y, d1, h1x, h1y), ok2 = hit_nb(g2, s10x, s10y, d2, h2x, h2y) && two;
+            if (ok1 && d1 < best) { best = d1; best_m = 8 * k + e1; bhx = h1x; bhy = h1y; }
+            if (ok2 && d2 < best) { best = d2; best_m = 8 * k + e2; bhx = h2x; bhy = h2y; }
+        }
+        merge(ga, ray, best, best_m, bhx, bhy);
+    }
+    const int no = s_cnt2[g];
+    for (int pi = r; pi < no; pi += 16) {
+        const int pr = s_pair[g * OBS_PAIRCAP + OBS_PAIRCAP - 1 - pi];
+        const int k = pr >> 4, ray = pr & 15;
+        const float s10x = s_rays[2 * ray] - 0.0f, s10y = s_rays[2 * ray + 1] - 0.0f;
+        SegGeom sg;
+        float dum0, dum1, d, hx, hy;
+        const int m = 8 * nn + (k - nn);
+        build(m, sg, dum0, dum1, false);
+        if (hit(sg, s10x, s10y, d, hx, hy)) merge(g, ray, d, m, hx, hy);
+    }
+    CA_OSTAMP(5);
+    wave_lds_sync();
+    CA_OSTAMP(6);
+    if (!active) return;
+    // ---- phase B: lane per ray ----
+    const unsigned long long key = s_key[g * 16 + r];
+    float bx = 0.0f, by = 0.0f, vx = 0.0f, vy = 0.0f;
+    if (key != ~0ull) {
+        SegGeom sg;
+        float wx, wy;
+        build((int)(unsigned)key, sg, wx, wy, true);
+        const float2 h = s_hit[g * 16 + r];
+        bx = h.x; by = h.y;
+        if (!(bx == 0.0f && by == 0.0f)) { vx = wx; vy = wy; }  // utils.py:103
+    }
+    CA_OSTAMP(7);
+    reinterpret_cast<float4*>(p.obs)[q * 16 + r] = make_float4(bx, by, vx, vy);
+    CA_OSTAMP(8);
+}
+
+}  // namespace ca

@@ -1,0 +1,418 @@
+// ca_step.h -- the solve kernel (neighbour search, ORCA lines, LP, integration, reward / done) and the reset kernels
+// Part of the HIP kernels of libcaenv.so (see ca_kernels.h for the overview and the numerics contract).
+#pragma once
+#include "ca_lp.h"
+#include "ca_lines.h"
+#include "ca_nbr.h"
+
+namespace ca {
+
+// LDS carve-up of the step kernel (bytes): lines | px py vx vy | misc ints
+// ST = 0: the LDS line table; ST > 0 (register lines): per wave an LP3 pool of POOL_SLOTS slots x
+// (ML lines + ML - 1 projected lines + a header), ML = ST + KMAX
+__host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S, int ST = 0, int KMAX = 0) {
+    if (ST > 0) return (size_t)(BS / 64) * (2 * (ST + KMAX)) * POOL_SLOTS * 16 + (size_t)BS * 32;
+    return (size_t)BS * ((size_t)(K + S) * 16 + 16 + 16);
+}
+
+// ============================================================================================
+// One environment step for every arena (SURVEY.md A5/A6 -> A10-A15 -> A16-A18 + A20).
+// actions != null : env.py:367-416 `step`;  actions == null : `orca_step` (env.py:447-450,
+// ALAN:631-636) followed by the done test of ALAN:118-121 unless CA_F_NODONE.
+// ============================================================================================
+
+// ST = 0: ORCA lines in the LDS table [K+S][BS] (any K <= 16, S <= 8).
+// ST > 0: ORCA lines in registers (ST obstacle slots + KMAX neighbour slots), LP2/LP1 fully unrolled,
+//         LP3 through a small per-wave LDS pool.  Needs S <= ST; ~8 KB of LDS per wave instead of
+//         16 KB; built for 4 waves per SIMD (<= 128 VGPRs), i.e. 16 waves per CU: the 4096 arenas
+//         of the C3 workload are all resident at once instead of taking 1.6 rounds at 10 per CU.
+template <int KMAX, int BS, int ST, bool FUSE>
+__global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs p) {
+    extern __shared__ float4 smem4[];
+    // FUSE: the neighbour search runs at the head of this kernel instead of in a launch of its own (one
+    // drain/fill less per step, and its dispatch skew overlaps useful work).  A lane later reads back only the
+    // lists of its own agent, which it wrote itself; the search's LDS arrays are not used again.
+    if constexpr (FUSE) nbr_body<KMAX, BS>(p);
+    constexpr int ML = ST + KMAX;  // register slots (ST > 0)
+    const int tid = threadIdx.x;
+    const int P = p.P;
+    const int la = tid >> p.logP;
+    const int i = tid & (P - 1);
+    const int apb = BS >> p.logP;
+    const int a = p.a0 + blockIdx.x * apb + la;
+    const bool frozen = arena_frozen(p, a);  // CA_F_FREEZE: the episode of this arena is over
+    const bool active = (a < p.a1) && (i < p.N) && !frozen;
+    if (frozen && i == 0) p.arena_stats[(size_t)a * ST_STRIDE + ST_FROZEN] += 1;
+    const int N = p.N, K = p.K, S = p.S;
+    const int q = active ? a * N + i : 0;
+    const int lbase = la << p.logP;
+
+    float4* s_lines = smem4;  // ST = 0: [(K+S)][BS];  ST > 0: [waves][2 ML][POOL_SLOTS] (last row: slot headers)
+    float* s_px = reinterpret_cast<float*>(
+        smem4 + (ST > 0 ? (size_t)(BS / 64) * (2 * ML) * POOL_SLOTS : (size_t)(K + S) * BS));
+    float* s_py = s_px + BS;
+    float* s_vx = s_py + BS;
+    float* s_vy = s_vx + BS;
+    int* s_misc = reinterpret_cast<int*>(s_vy + BS);            // [BS][4]
+    LdsLines ls; ls.base = s_lines + tid; ls.stride = BS;       // (ST = 0 only)
+
+    CA_STAMP(0);
+    // ---- load own state (coalesced SoA) ----
+    V2 pos = mk(0.0f, 0.0f), vel = mk(0.0f, 0.0f), pref = mk(0.0f, 0.0f);
+    double gx = 0.0, gy = 0.0;
+    int done = 1;
+    double pf_x = 1.0, pf_y = 0.0, rl_x = 1.0, rl_y = 0.0;
+    if (active) {
+        pos = mk(p.pos_x[q], p.pos_y[q]);
+        vel = mk(p.vel_x[q], p.vel_y[q]);
+        gx = p.goal_x[q]; gy = p.goal_y[q];
+        done = p.agent_done[q];
+        if (p.actions) {  // env.py:371-383
+            pref_dir64(pos.x, pos.y, gx, gy, &pf_x, &pf_y);
+            double sn, cs;
+            sincos64((double)p.actions[q], &sn, &cs);
+            rl_x = pf_x * cs - pf_y * sn;
+            rl_y = pf_x * sn + pf_y * cs;
+            pref = mk((float)rl_x, (float)rl_y);
+        } else {
+            pref = mk(p.pref_x[q], p.pref_y[q]);
+        }
+    }
+    s_px[tid] = pos.x; s_py[tid] = pos.y; s_vx[tid] = vel.x; s_vy[tid] = vel.y;
+    __syncthreads();
+
+    CA_STAMP(1);
+    // ---- neighbour lists of this step (App. A.2), produced by nbr_kernel ----
+    const int ocnt = active ? p.obst_count[q] : 0;
+    const int ncnt = active ? p.nb_count[q] : 0;
+    CA_STAMP(2);
+    CA_STAMP(3);
+    const float R = p.radius;
+    V2 nv = mk(0.0f, 0.0f);
+    if constexpr (ST > 0) {
+        // ================= register path =================
+        float4 L[ML];
+        static_for<ML>([&](auto kc) __attribute__((always_inline)) { L[decltype(kc)::value] = make_float4(0.0f, 0.0f, 1.0f, 0.0f); });
+        int no = 0;  // obstacle lines produced so far (slots [0, no))
+        {
+            const float invTO = 1.0f / p.time_horizon_obst;
+            int e_next = (ocnt > 0) ? p.obst_idx[((size_t)a * S + 0) * N + i] : 0;
+            for (int s = 0; s < S; ++s) {
+                if (s < ocnt) {
+                    const int e = e_next;
+                    if (s + 1 < ocnt) e_next = p.obst_idx[((size_t)a * S + (s + 1)) * N + i];
+                    auto covered = [&](V2 c1, V2 c2) __attribute__((always_inline)) {
+                        bool c = false;
+                        static_for<ST>([&](auto jc) __attribute__((always_inline)) {
+                            constexpr int j = decltype(jc)::value;
+                            const Line M = unpack_line(L[j]);
+                            if (j < no && det(c1 - M.point, M.dir) - invTO * R >= -EPS &&
+                                det(c2 - M.point, M.dir) - invTO * R >= -EPS)
+                                c = true;
+                        });
+                        return c;
+                    };
+                    Line line;
+                    if (obst_orca_line(p.obst, e, pos, vel, R, invTO, covered, line)) {
+                        const float4 pl = pack_line(line);
+                        static_for<ST>([&](auto jc) __attribute__((always_inline)) {
+                            constexpr int j = decltype(jc)::value;
+                            if (j == no) L[j] = pl;  // (a ?: on the struct type would select between addresses)
+                        });
+                        ++no;
+                    }
+                }
+            }
+        }
+        CA_STAMP(4);
+        {
+            const float invT = 1.0f / p.time_horizon;
+            const float invDt = 1.0f / p.time_step;
+            int jn[KMAX];  // all neighbour indices in flight at once
+            static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                jn[k] = (k < ncnt) ? p.nb_idx[((size_t)a * K + k) * N + i] : 0;
+            });
+            static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
+                constexpr int k = decltype(kc)::value;
+                if (k < ncnt) {
+                    const int j = lbase + jn[k];
+                    L[ST + k] = pack_line(agent_orca_line(pos, vel, mk(s_px[j], s_py[j]), mk(s_vx[j], s_vy[j]), R, invT, invDt));
+                }
+            });
+        }
+        CA_STAMP(5);
+        // ---- 2-D linear program (App. A.5) on the register slots ----
+        const int nl = no + ncnt;
+        int fail = nl;
+        if (active) fail = lp2_reg<ML, ST>(L, no, ncnt, p.max_speed, pref, nv);
+        CA_STAMP(6);
+        // ---- LP3 for the lanes whose LP2 was infeasible: they copy their lines into a slot of the
+        // wave's LDS pool and solve there; more than POOL_SLOTS such lanes take further rounds ----
+        {
+            float4* pool = s_lines + (size_t)(tid >> 6) * (2 * ML) * POOL_SLOTS;
+            float4* hdr = pool + (size_t)(2 * ML - 1) * POOL_SLOTS;
+            bool need = active && fail < nl;
+            const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+            while (true) {
+                const unsigned long long m = __ballot(need);
+                if (!m) break;
+                const int rank = __popcll(m & below);
+                const bool mine = need && rank < POOL_SLOTS;
+                if (mine) {
+                    LdsLines pls; pls.base = pool + rank; pls.stride = POOL_SLOTS;
+                    static_for<ML>([&](auto kc) __attribute__((always_inline)) {
+                        constexpr int k = decltype(kc)::value;
+                        const bool valid = (k < ST) ? (k < no) : (k - ST < ncnt);
+                        if (valid) pls.base[((k < ST) ? k : no + (k - ST)) * POOL_SLOTS] = L[k];
+                    });
+                    hdr[rank] = make_float4(nv.x, nv.y, __int_as_float(nl | (no << 8) | (fail << 16)), 0.0f);
+                }
+                wave_lds_sync();
+                const int waiting = __popcll(m);
+                lp3_coop(pool, ML, waiting < POOL_SLOTS ? waiting : POOL_SLOTS, p.max_speed);  // the whole wave works
+                wave_lds_sync();
+                if (mine) {
+                    const float4 h = hdr[rank];
+                    nv = mk(h.x, h.y);
+                    need = false;
+                }
+            }
+        }
+    } else {
+        // ================= LDS-table path =================
+        int nl = 0;
+    {
+        const float invTO = 1.0f / p.time_horizon_obst;
+        int e_next = (ocnt > 0) ? p.obst_idx[((size_t)a * S + 0) * N + i] : 0;
+        for (int s = 0; s < S; ++s) {
+            if (s < ocnt) {
+                const int e = e_next;
+                if (s + 1 < ocnt) e_next = p.obst_idx[((size_t)a * S + (s + 1)) * N + i];
+                Line line;
+                auto covered = [&](V2 c1, V2 c2) {
+                    for (int j = 0; j < nl; ++j) {
+                        const Line M = ls.get(j);
+                        if (det(c1 - M.point, M.dir) - invTO * R >= -EPS && det(c2 - M.point, M.dir) - invTO * R >= -EPS)
+                            return true;
+                    }
+                    return false;
+                };
+                if (obst_orca_line(p.obst, e, pos, vel, R, invTO, covered, line)) {
+                    ls.put(nl, line);
+                    ++nl;
+                }
+            }
+        }
+    }
+    const int numObstLines = nl;
+    CA_STAMP(4);
+    {
+        const float invT = 1.0f / p.time_horizon;
+        const float invDt = 1.0f / p.time_step;
+        int j_next = (ncnt > 0) ? p.nb_idx[((size_t)a * K + 0) * N + i] : 0;
+        for (int k = 0; k < K; ++k) {
+            if (k < ncnt) {
+                const int j = lbase + j_next;
+                if (k + 1 < ncnt) j_next = p.nb_idx[((size_t)a * K + (k + 1)) * N + i];
+                const Line line = agent_orca_line(pos, vel, mk(s_px[j], s_py[j]), mk(s_vx[j], s_vy[j]), R, invT, invDt);
+                ls.put(nl, line);
+                ++nl;
+            }
+        }
+    }
+
+    CA_STAMP(5);
+    // ---- 2-D linear program (App. A.5) ----
+    int fail = nl;
+    if (active) fail = lp2(ls, nl, p.max_speed, pref, false, nv);
+    CA_STAMP(6);
+    if (active && fail < nl) lp3<KMAX + SMAX>(ls, nl, numObstLines, fail, p.max_speed, nv);
+    }
+    if (active) {  // ---- integrate (App. A.1) ----
+        vel = nv;
+        pos = pos + vel * p.time_step;
+    }
+    CA_STAMP(7);
+
+    __syncthreads();  // every lane is done with the pre-step arena image
+    s_px[tid] = pos.x; s_py[tid] = pos.y;
+    s_misc[tid * 4 + 0] = 0; s_misc[tid * 4 + 1] = 0; s_misc[tid * 4 + 2] = 0; s_misc[tid * 4 + 3] = 0;
+    __syncthreads();
+    int* red = s_misc + la * 4;  // per-arena: [0] not-done agents, [1] pairs, [2] wall hits, [3] goals
+
+    if (active) {
+        if (p.flags & 2u) {  // CA_F_STATS
+            int pairs = 0;
+            const float crSq = sqr(R + R);
+            for (int j = i + 1; j < N; ++j)
+                if (absSq(pos - mk(s_px[lbase + j], s_py[lbase + j])) < crSq) ++pairs;
+            bool wall = false;
+            for (int e = 0; e < p.n_obst; ++e) {
+                const ObstDev o1 = p.obst[e];
+                if (distSqPointSegment(mk(o1.px, o1.py), mk(o1.qx, o1.qy), pos) < sqr(R)) wall = true;
+            }
+            if (pairs) atomicAdd(&red[1], pairs);
+            if (wall) atomicAdd(&red[2], 1);
+        }
+    }
+
+    CA_STAMP(8);
+    // ---- reward (env.py:389-400) or preferred velocity towards the goal (env.py:449) ----
+    float rew = 0.0f;
+    if (active) {
+        if (p.actions) {
+            const float scale = (float)p.reward_scale;
+            const float r_goal = vel.x * (float)pf_x + vel.y * (float)pf_y;
+            const float r_polite = vel.x * (float)rl_x + vel.y * (float)rl_y;
+            rew = scale * r_goal + (1.0f - scale) * r_polite;
+            p.reward[q] = rew;
+        } else {
+            double dx, dy;
+            pref_dir64(pos.x, pos.y, gx, gy, &dx, &dy);
+            pref = mk((float)dx, (float)dy);
+        }
+    }
+
+    CA_STAMP(9);
+    // ---- step counter and done test (env.py:352-365, 404-410; ALAN:118-121, 547-566) ----
+    const bool nodone = (p.flags & 8u) != 0;  // CA_F_NODONE
+    bool goal_changed = false;
+    int steps = active ? p.step_count[a] : 0;
+    if (!p.actions && !nodone) ++steps;
+    if (active && !nodone) {
+        bool hit = false;
+        if (p.done_mode == 0) {
+            hit = (done == 0) && (pos.x < p.done_x_thresh);
+        } else {
+            const double dx = (double)pos.x - gx, dy = (double)pos.y - gy;
+            const double lim = 2.0 * (double)p.radius;
+            hit = (dx * dx + dy * dy) < lim * lim;
+            if (p.done_mode == 1) hit = hit && (done == 0);
+        }
+        if (hit) {
+            if (p.done_mode == 2) {
+                const int rc = p.regoal_count[q];
+                double u0, u1;
+                rng2(p.seed, p.arena_offset + a, i, RNG_REGOAL, (uint32_t)rc, &u0, &u1);
+                gx = uniform64((double)p.goal_x0, (double)p.goal_x1, u0);
+                gy = uniform64((double)p.goal_y0, (double)p.goal_y1, u1);
+                p.regoal_count[q] = rc + 1;
+            } else {
+                done = 1;
+                p.arrive_step[q] = steps;
+                gx = p.goal2_x[q]; gy = p.goal2_y[q];
+                p.agent_done[q] = 1;
+            }
+            p.goal_x[q] = gx; p.goal_y[q] = gy;
+            goal_changed = true;
+            atomicAdd(&red[3], 1);
+        }
+    }
+    if (p.actions) ++steps;
+    if (active && done == 0) atomicAdd(&red[0], 1);
+    __syncthreads();
+
+    bool all_done = false;
+    if (active) {
+        all_done = !nodone && (red[0] == 0);
+        if (p.max_step > 0 && steps >= p.max_step) all_done = true;
+    }
+    const bool do_reset = all_done && (p.flags & 4u);  // CA_F_AUTORESET
+    int epi = 0;
+    if (do_reset) {  // env.py:461-488 for this arena
+        epi = p.episode[a];
+        double u0, u1;
+        rng2(p.seed, p.arena_offset + a, i, RNG_RESET, (uint32_t)epi, &u0, &u1);
+        pos = mk((float)uniform64((double)p.spawn_x0, (double)p.spawn_x1, u0),
+                 (float)uniform64((double)p.spawn_y0, (double)p.spawn_y1, u1));
+        done = 0;
+        p.agent_done[q] = 0;
+        double dx, dy;
+        pref_dir64(pos.x, pos.y, gx, gy, &dx, &dy);
+        pref = mk((float)dx, (float)dy);
+    }
+    // sum of rewards: fixed-shape tree inside the wave, then per-arena in lane order
+    if (p.actions && (p.flags & 2u)) {
+        double r = active ? (double)rew : 0.0;
+        const int w = P < 64 ? P : 64;
+        for (int off = w >> 1; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
+        if (active && (i & 63) == 0)
+            atomicAdd(reinterpret_cast<double*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_SUMREW]), r);
+    }
+    // orientation of the observation frame (env.py:236): direction to the goal from the final state.
+    // After an ORCA-only step or a reset `pref` already is that vector; otherwise derive it here, once
+    // per agent, instead of in each of the 16 ray lanes of the observation kernel.
+    float ox = pref.x, oy = pref.y;
+    if (active && !do_reset && (p.actions != nullptr || goal_changed)) {
+        double dx, dy;
+        pref_dir64(pos.x, pos.y, gx, gy, &dx, &dy);
+        ox = (float)dx; oy = (float)dy;
+    }
+    CA_STAMP(10);
+    __syncthreads();  // all lanes have read red[] and episode[]
+    if (active) {
+        p.orient_x[q] = ox; p.orient_y[q] = oy;
+        p.pos_x[q] = pos.x; p.pos_y[q] = pos.y;
+        p.vel_x[q] = vel.x; p.vel_y[q] = vel.y;
+        p.pref_x[q] = pref.x; p.pref_y[q] = pref.y;
+        if (i == 0) {
+            unsigned long long* st = p.arena_stats + (size_t)a * ST_STRIDE;
+            if (red[1]) st[ST_COLL] += (unsigned)red[1];
+            if (red[2]) st[ST_OBST_COLL] += (unsigned)red[2];
+            if (red[3]) st[ST_GOALS] += (unsigned)red[3];
+            if (all_done) {  // + what a caller that auto-resets wants to know about the episode that ended
+                st[ST_EPISODES] += 1;
+                st[ST_LASTEP] = ((unsigned long long)(unsigned)steps << 32) | (unsigned)(N - red[0]);
+            }
+            p.arena_done[a] = all_done ? 1 : 0;
+            p.step_count[a] = do_reset ? 0 : steps;
+            if (do_reset) p.episode[a] = epi + 1;
+        }
+    }
+    CA_STAMP(11);
+}
+
+// ============================================================================================
+// reset() for every arena (env.py:461-488): new positions only; velocities, targets and the
+// neighbour lists of the last step stay.
+// ============================================================================================
+__global__ void reset_kernel(const StepArgs p) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= p.A * p.N) return;
+    const int a = q / p.N, i = q - a * p.N;
+    if (p.reset_mask && p.reset_mask[a] == 0) return;
+    V2 pos;
+    if (p.reset_px) {
+        pos = mk(p.reset_px[q], p.reset_py[q]);
+    } else {
+        double u0, u1;
+        rng2(p.seed, p.arena_offset + a, i, RNG_RESET, (uint32_t)p.episode[a], &u0, &u1);
+        pos = mk((float)uniform64((double)p.spawn_x0, (double)p.spawn_x1, u0),
+                 (float)uniform64((double)p.spawn_y0, (double)p.spawn_y1, u1));
+    }
+    double dx, dy;
+    pref_dir64(pos.x, pos.y, p.goal_x[q], p.goal_y[q], &dx, &dy);
+    p.pos_x[q] = pos.x; p.pos_y[q] = pos.y;
+    p.pref_x[q] = (float)dx; p.pref_y[q] = (float)dy;
+    p.orient_x[q] = (float)dx; p.orient_y[q] = (float)dy;
+    p.agent_done[q] = 0;
+}
+// orientation from scratch (after the caller overwrote positions or goals through ca_set)
+__global__ void orient_kernel(const StepArgs p) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= p.A * p.N) return;
+    double dx, dy;
+    pref_dir64(p.pos_x[q], p.pos_y[q], p.goal_x[q], p.goal_y[q], &dx, &dy);
+    p.orient_x[q] = (float)dx; p.orient_y[q] = (float)dy;
+}
+__global__ void reset_arena_kernel(const StepArgs p) {  // after reset_kernel: per-arena counters
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= p.A) return;
+    if (p.reset_mask && p.reset_mask[a] == 0) return;
+    p.step_count[a] = 0;
+    p.arena_done[a] = 0;
+    p.episode[a] += 1;
+}
+
+}  // namespace ca
