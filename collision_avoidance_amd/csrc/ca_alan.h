@@ -18,9 +18,9 @@ struct AlanArgs {
     const float *pos_x, *pos_y, *vel_x, *vel_y;
     const double *goal_x, *goal_y;
     float *pref_x, *pref_y, *reward;
-    double *w, *t;        // [A*N][nA] action weights / time since the action's weight was set
+    double *w, *t;        // [A][nA][N] action weights / time since the action's weight was set
     int* action;          // [A*N] the action of the current step (complemented while its arena sits out a step)
-    double* dirs;         // [A*N][4] goal direction and rotated direction of the current step
+    double* dirs;         // [4][A*N] goal direction and rotated direction of the current step
     const double* u;      // [A*N] caller-supplied uniforms in [0,1), or null: Philox (RNG_ALAN, step)
     const int *step_count, *arena_done;
     unsigned long long* arena_stats;
@@ -53,7 +53,7 @@ __device__ __forceinline__ double np_sum(int n, Get get) {
 }
 
 __global__ __launch_bounds__(ALAN_BS) void alan_select_kernel(const AlanArgs p) {
-    __shared__ double s_ps[ALAN_MAX_ACTIONS * ALAN_BS];  // [action][lane]
+    extern __shared__ double s_ps[];  // [n_actions][lane]: sized by the launch (8 B x n_actions x ALAN_BS)
     const int q = blockIdx.x * ALAN_BS + threadIdx.x;
     if (q >= p.A * p.N) return;
     const int a = q / p.N, i = q - a * p.N, nA = p.nA;
@@ -62,8 +62,9 @@ __global__ __launch_bounds__(ALAN_BS) void alan_select_kernel(const AlanArgs p) 
         return;
     }
     double* ps = s_ps + threadIdx.x;
-    const double* w = p.w + (size_t)q * nA;
-    for (int k = 0; k < nA; ++k) ps[k * ALAN_BS] = exp64(w[k] / p.temp);           // ALAN:580-581
+    // weights and times are stored [A][n_actions][N]: the lanes of a wave read consecutive doubles
+    const double* w = p.w + (size_t)a * nA * p.N + i;
+    for (int k = 0; k < nA; ++k) ps[k * ALAN_BS] = exp64(w[(size_t)k * p.N] / p.temp);  // ALAN:580-581
     const double sum = np_sum(nA, [&](int k) { return ps[k * ALAN_BS]; });
     double acc = 0.0;
     for (int k = 0; k < nA; ++k) {                                                 // ALAN:582
@@ -87,8 +88,8 @@ __global__ __launch_bounds__(ALAN_BS) void alan_select_kernel(const AlanArgs p) 
     pref_dir64(p.pos_x[q], p.pos_y[q], p.goal_x[q], p.goal_y[q], &gx, &gy);        // ALAN:588
     const double cs = p.act_c[id], sn = p.act_s[id];                                // ALAN:592-595
     const double lx = gx * cs - gy * sn, ly = gx * sn + gy * cs;
-    double* d = p.dirs + (size_t)q * 4;
-    d[0] = gx; d[1] = gy; d[2] = lx; d[3] = ly;
+    const size_t an = (size_t)p.A * p.N;  // dirs: [4][A*N]
+    p.dirs[q] = gx; p.dirs[an + q] = gy; p.dirs[2 * an + q] = lx; p.dirs[3 * an + q] = ly;
     p.pref_x[q] = (float)lx; p.pref_y[q] = (float)ly;                               // ALAN:598
 }
 
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(ALAN_BS) void alan_update_kernel(const AlanArgs p) 
         return;
     }
     const int a = q / p.N, nA = p.nA;
-    const double* d = p.dirs + (size_t)q * 4;
+    const size_t an = (size_t)p.A * p.N;
+    const double d[4] = {p.dirs[q], p.dirs[an + q], p.dirs[2 * an + q], p.dirs[3 * an + q]};
     const float vxf = p.vel_x[q], vyf = p.vel_y[q];
     {   // env.py:389-400 in fp32, as ca_step reports it
         const float scale = (float)p.reward_scale;
@@ -114,14 +116,15 @@ __global__ __launch_bounds__(ALAN_BS) void alan_update_kernel(const AlanArgs p) 
     }
     const double vx = (double)vxf, vy = (double)vyf;                                // ALAN:606-613
     const double R = p.reward_scale * (vx * d[0] + vy * d[1]) + (1.0 - p.reward_scale) * (vx * d[2] + vy * d[3]);
-    double* w = p.w + (size_t)q * nA;
-    double* t = p.t + (size_t)q * nA;
+    const int i = q - a * p.N;
+    double* w = p.w + (size_t)a * nA * p.N + i;
+    double* t = p.t + (size_t)a * nA * p.N + i;
     for (int k = 0; k < nA; ++k) {                                                  // ALAN:616-628
-        double tk = t[k] + p.dt;
-        double wk = w[k];
+        double tk = t[(size_t)k * p.N] + p.dt;
+        double wk = w[(size_t)k * p.N];
         if (tk >= p.window) { tk = 0.0; wk = 0.0; }
         if (k == id) wk = R;
-        t[k] = tk; w[k] = wk;
+        t[(size_t)k * p.N] = tk; w[(size_t)k * p.N] = wk;
     }
     // the solve kernel left the goal direction in pref (its ORCA-mode epilogue); the reference's agent
     // still holds the velocity it was given at ALAN:598

@@ -839,7 +839,7 @@ int ca_alan_step(ca_env* e, const double* u, int32_t u_is_device, uint32_t flags
     const dim3 grid((unsigned)((AN(e) + ALAN_BS - 1) / ALAN_BS)), block(ALAN_BS);
     {
         ProfScope ps(e, KIND_RESET);
-        hipLaunchKernelGGL(alan_select_kernel, grid, block, 0, e->stream, p);
+        hipLaunchKernelGGL(alan_select_kernel, grid, block, (size_t)e->n_actions * ALAN_BS * 8, e->stream, p);
     }
     HIPCHK(e, hipGetLastError());
     StepArgs a;

@@ -108,7 +108,7 @@ class VecCollisionAvoidanceEnv:
         if field == _lib.FLD_OBS:
             return (self.A, self.N, _lib.OBS_DIM), dt
         if field in (_lib.FLD_ALAN_WEIGHTS, _lib.FLD_ALAN_TIMES):
-            return (self.A, self.N, self.n_actions), dt
+            return (self.A, self.n_actions, self.N), dt      # device layout; get()/set() present [A, N, n_actions]
         return (self.A, self.N), dt
 
     def get(self, field):
@@ -116,10 +116,14 @@ class VecCollisionAvoidanceEnv:
         shape, dt = self._shape_dtype(field)
         out = np.empty(shape, dt)
         self._call("ca_get", self.h, field, _ptr(out), out.nbytes, 0)
+        if field in (_lib.FLD_ALAN_WEIGHTS, _lib.FLD_ALAN_TIMES):
+            return np.ascontiguousarray(np.transpose(out, (0, 2, 1)))   # [A, N, n_actions] like ALAN_true.py:75-76
         return out
 
     def set(self, field, arr):
         shape, dt = self._shape_dtype(field)
+        if field in (_lib.FLD_ALAN_WEIGHTS, _lib.FLD_ALAN_TIMES):
+            arr = np.transpose(np.asarray(arr, dt).reshape(self.A, self.N, self.n_actions), (0, 2, 1))
         a = np.ascontiguousarray(np.asarray(arr, dt).reshape(shape))
         self._call("ca_set", self.h, field, _ptr(a), a.nbytes, 0)
 

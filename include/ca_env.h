@@ -84,8 +84,9 @@ enum ca_field {
     CA_FLD_ARENA_DONE,   /* i32 [A]                                               */
     CA_FLD_EPISODE,      /* i32 [A]                                               */
     CA_FLD_REGOAL_COUNT, /* i32 [A,N]                                             */
-    CA_FLD_ALAN_WEIGHTS, /* f64 [A,N,n_actions] ALAN:75 self.weights (after ca_alan_configure)     */
-    CA_FLD_ALAN_TIMES,   /* f64 [A,N,n_actions] ALAN:76 self.times                                 */
+    CA_FLD_ALAN_WEIGHTS, /* f64 [A,n_actions,N] ALAN:75 self.weights (after ca_alan_configure);
+                            agent index fastest like every other per-agent array                  */
+    CA_FLD_ALAN_TIMES,   /* f64 [A,n_actions,N] ALAN:76 self.times                                 */
     CA_FLD_ALAN_ACTION,  /* i32 [A,N] the action executed by the last ca_alan_step (read-only)     */
     CA_FLD_ARENA_STATS,  /* u64 [A,8] per-arena counters (read-only): episodes, collisions, obst_collisions,
                             goals_reached, obst_overflow, sum_reward (f64 bits), steps sat out under
