@@ -30,6 +30,11 @@ __device__ __forceinline__ double make_key(float d, int idx) {
 }
 __device__ __forceinline__ float key_dist(double k) { return __uint_as_float((unsigned)((unsigned long long)__double_as_longlong(k) >> 32)); }
 __device__ __forceinline__ int key_index(double k) { return (int)(unsigned)(unsigned long long)__double_as_longlong(k); }
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 template <int MAXN>
 __device__ __forceinline__ void sorted_insert(double (&key)[MAXN], double x) {
 #pragma unroll
@@ -173,6 +178,52 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
                     }
                 }
             }
+            scanned = true;
+        }
+    }
+    if (K > 0 && !scanned && N <= 64) {
+        // Arenas of at most 64 agents: 32-bit composite keys = (fixed-point distance << logP) | candidate index and
+        // one v_med3_u32 per list slot and candidate -- new[k] = med3(old[k-1], old[k], x) IS the sorted insert,
+        // at half the instructions of the 64-bit network (in so small an arena some lane accepts nearly every
+        // candidate, so the shrinking range of the contract never lets a wave skip the network anyway).  The
+        // fixed-point value floor(d2 * 2^(32-logP) / neighbor_dist^2) is only a MONOTONE image of the fp32
+        // distance, so the composite order can differ from the exact (distance, index) order only between
+        // candidates with the same image.  The list therefore keeps one extra slot (the (K+1)-th smallest), and a
+        // lane whose K+1 smallest composites have pairwise different images provably holds the exact list:
+        // strictly increasing images order the first K exactly and put every other candidate behind them.  A
+        // wave in which some lane fails that test (exact fp32 ties, e.g. the symmetric circle world; ~2e-3 of the
+        // waves of a random crowd) falls through to the exact 64-bit scan below.
+        const float rangeSq0 = sqr(p.neighbor_dist);
+        const unsigned lowmask = (unsigned)(P - 1);
+        const float fx_scale = 0.999f * (float)(1u << (31 - p.logP)) * 2.0f / rangeSq0;  // image < 2^(32-logP) - 1
+        unsigned ck[KMAX + 1];
+#pragma unroll
+        for (int k = 0; k <= KMAX; ++k) ck[k] = (k < kofs) ? 0u : 0xFFFFFFFFu;
+        V2 o_next = mk(s_px[lbase], s_py[lbase]);
+        for (int j = 0; j < N; ++j) {
+            const V2 o = o_next;
+            if (j + 1 < N) o_next = mk(s_px[lbase + j + 1], s_py[lbase + j + 1]);
+            const float dsq = absSq(pos - o);
+            const bool pass = active && j != i && dsq < rangeSq0;
+            const unsigned c = pass ? (((unsigned)(dsq * fx_scale) << p.logP) | (unsigned)j) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = KMAX; k >= 1; --k) ck[k] = umed3(ck[k - 1], ck[k], c);
+            ck[0] = ck[0] < c ? ck[0] : c;
+        }
+        bool near_tie = false;
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k >= kofs) {
+                if (ck[k] != 0xFFFFFFFFu) ++cnt;
+                if (ck[k + 1] != 0xFFFFFFFFu && ((ck[k] ^ ck[k + 1]) <= lowmask)) near_tie = true;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(near_tie) == 0ull) {  // wave-uniform
+            ncnt = cnt;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)  // hand the indices over in the key array the store below reads
+                nkey[k] = (k < kofs) ? KEY_DUMMY : make_key(0.0f, (ck[k] == 0xFFFFFFFFu) ? -1 : (int)(ck[k] & lowmask));
             scanned = true;
         }
     }
