@@ -343,3 +343,35 @@ def test_processed_obstacle_table_equals_oracle():
         np.testing.assert_array_equal(tg["verts"][:, 0], te["px"]); np.testing.assert_array_equal(tg["verts"][:, 1], te["py"])
         np.testing.assert_array_equal(tg["next"], te["next"]); np.testing.assert_array_equal(tg["convex"], te["convex"])
         g.close()
+
+
+def test_run_to_run_determinism():
+    """Two handles with the same configuration, seed and actions stay bit-identical (no dependence on wave timing,
+    atomics order or which lane of a wave wins a merge): state, neighbour lists, observation, reward, counters."""
+    from collision_avoidance_amd import _lib
+    A, N = 256, 64
+    p = scenarios.bench_params(N, 5.0, 10)
+    g1 = H.make_gpu(A, N, "crowd", p, seed=21)
+    g2 = H.make_gpu(A, N, "crowd", p, seed=21)
+    rng = np.random.RandomState(5)
+    fields = [_lib.FLD_POS_X, _lib.FLD_POS_Y, _lib.FLD_VEL_X, _lib.FLD_VEL_Y, _lib.FLD_GOAL_X, _lib.FLD_NB_COUNT, _lib.FLD_NB_IDX,
+              _lib.FLD_OBST_COUNT, _lib.FLD_OBST_IDX, _lib.FLD_OBS, _lib.FLD_REWARD, _lib.FLD_REGOAL_COUNT]
+    for s in range(120):
+        act = rng.uniform(-0.5, 0.5, (A, N)).astype(np.float32)
+        g1.step(act, stats=True); g2.step(act, stats=True)
+        if s % 20 == 19:
+            for f in fields:
+                a, b = g1.get(f), g2.get(f)
+                if f == _lib.FLD_NB_IDX:   # entries beyond the count are unspecified
+                    cnt = g1.get(_lib.FLD_NB_COUNT)
+                    mask = np.arange(a.shape[1])[None, :, None] < cnt[:, None, :]
+                    a, b = np.where(mask, a, -1), np.where(mask, b, -1)
+                if f == _lib.FLD_OBST_IDX:
+                    cnt = g1.get(_lib.FLD_OBST_COUNT)
+                    mask = np.arange(a.shape[1])[None, :, None] < cnt[:, None, :]
+                    a, b = np.where(mask, a, -1), np.where(mask, b, -1)
+                assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                                      b.view(np.uint32) if b.dtype == np.float32 else b), (s, f)
+    s1, s2 = g1.stats(), g2.stats()
+    assert all(s1[k] == s2[k] for k in s1 if k != "sum_reward")
+    g1.close(); g2.close()
