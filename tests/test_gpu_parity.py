@@ -375,3 +375,43 @@ def test_run_to_run_determinism():
     s1, s2 = g1.stats(), g2.stats()
     assert all(s1[k] == s2[k] for k in s1 if k != "sum_reward")
     g1.close(); g2.close()
+
+
+def test_plain_c_client_of_the_abi(tmp_path):
+    """tests/abi/c_client.c drives the library through include/ca_env.h from plain C (gcc, no Python, no HIP
+    headers); its checksum of state, reward and observation equals the same run through the ctypes binding."""
+    import shutil
+    import subprocess
+    from collision_avoidance_amd import _lib
+    from collision_avoidance_amd import build as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(B.LIB_PATH)
+    exe = str(tmp_path / "c_client")
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    subprocess.check_call([gcc, "-std=c99", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "abi", "c_client.c"),
+                           "-o", exe, "-L" + libdir, "-lcaenv", "-lm", "-Wl,-rpath," + libdir])
+    A, N, steps = 8, 10, 40
+    out = subprocess.run([exe, str(A), str(N), str(steps)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    c_hash, c_steps, c_coll = out.stdout.split()
+
+    def fnv(h, a):
+        for b in np.ascontiguousarray(a).view(np.uint8).reshape(-1).tolist():
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    env = H.make_gpu(A, N, "doorway", H.scenario_params("doorway", N), seed=7, max_obst_neighbors=8)
+    env.reset()
+    lcg = 12345
+    for s in range(steps):
+        act = np.empty(A * N, np.float32)
+        for q in range(A * N):
+            lcg = (lcg * 1664525 + 1013904223) & 0xFFFFFFFF
+            act[q] = (np.float32(lcg >> 8) / np.float32(16777216.0) - np.float32(0.5)) * np.float32(1.5)
+        env.step(act.reshape(A, N), stats=True)
+    h = 1469598103934665603
+    for f in (_lib.FLD_POS_X, _lib.FLD_POS_Y, _lib.FLD_REWARD, _lib.FLD_OBS):
+        h = fnv(h, env.get(f))
+    st = env.stats()
+    assert (int(c_hash, 16), int(c_steps), int(c_coll)) == (h, st["agent_steps"], st["collisions"])
+    env.close()
