@@ -415,3 +415,29 @@ def test_plain_c_client_of_the_abi(tmp_path):
     st = env.stats()
     assert (int(c_hash, 16), int(c_steps), int(c_coll)) == (h, st["agent_steps"], st["collisions"])
     env.close()
+
+
+def test_world_without_obstacles_and_ragged_edges():
+    """Empty obstacle table (no walls at all), a single agent per arena next to a wall, and an arena count that
+    does not fill the last workgroup: the ragged and empty cases of the reference's own usage."""
+    from collision_avoidance_amd import _lib
+    p = H.scenario_params("crowd", 9)
+    g = H.make_gpu(7, 9, "crowd", p, seed=2, polys=[], max_obst_neighbors=1)
+    e = H.make_oracle(7, 9, "crowd", p, seed=2, polys=[], max_obst_neighbors=1)
+    g.reset(); e.reset()
+    rng = np.random.RandomState(0)
+    for s in range(120):
+        act = rng.uniform(-1, 1, (7, 9)).astype(np.float32)
+        g.step(act, stats=True); e.step(act, flags=o.F_OBS | o.F_STATS)
+    H.assert_state_equal(g, e, "no obstacles", obs=True, reward=True)
+    H.assert_stats_equal(g, e, "no obstacles")
+    assert g.obstacle_table()["verts"].shape == (0, 2) and (g.get(_lib.FLD_OBST_COUNT) == 0).all()
+    g.close()
+    p1 = H.scenario_params("crowd", 1)
+    g = H.make_gpu(67, 1, "crowd", p1, seed=3)      # 67 arenas x 1 lane: two workgroups, the second nearly empty
+    e = H.make_oracle(67, 1, "crowd", p1, seed=3)
+    for s in range(200):
+        g.orca_step(with_obs=True, stats=True); e.orca_step(flags=o.F_OBS | o.F_STATS)
+    H.assert_state_equal(g, e, "single agents", obs=True)
+    H.assert_stats_equal(g, e, "single agents")
+    g.close()
