@@ -188,3 +188,21 @@ def test_reset_draws_a_new_world_and_batched_evaluation():
             seq.reset(acts)
         tts.append(seq.run_sim(1)[2])
     assert ok == 3 and abs(mean_tt - float(np.mean(tts))) < 1e-12
+
+
+def test_alan_error_behaviour():
+    env = H.make_gpu(2, 4, "crowd", H.scenario_params("crowd", 4))
+    with pytest.raises(RuntimeError, match="ca_alan_configure first"):
+        env.alan_step()
+    with pytest.raises(RuntimeError):
+        env.get(_lib.FLD_ALAN_ACTION)                     # no bandit state yet
+    with pytest.raises(RuntimeError, match="out of range"):
+        env.alan_configure([(1, 0)] * 33)
+    with pytest.raises(RuntimeError, match="positive"):
+        env.alan_configure([(1, 0), (0, 1)], temp=0.0)
+    env.alan_configure([(1, 0), (0, 0)])                  # a zero action vector means "no rotation" (atan2(0, 0) = 0)
+    env.alan_step()
+    assert env.get(_lib.FLD_ALAN_WEIGHTS).shape == (2, 4, 2)
+    with pytest.raises(RuntimeError, match="do not apply"):
+        env._call("ca_alan_step", env.h, None, 0, _lib.F_AUTORESET)
+    env.close()
