@@ -111,8 +111,17 @@ __global__ __launch_bounds__(ALAN_BS) void alan_update_kernel(const AlanArgs p) 
         const float r_polite = vxf * (float)d[2] + vyf * (float)d[3];
         const float rew = scale * r_goal + (1.0f - scale) * r_polite;
         p.reward[q] = rew;
-        if (p.flags & 2u)
-            atomicAdd(reinterpret_cast<double*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_SUMREW]), (double)rew);
+        if (p.flags & 2u) {
+            double* sum = reinterpret_cast<double*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_SUMREW]);
+            if ((p.N & 63) == 0) {  // a wave lies inside one arena (and leaves the kernel as a whole): one atomic per wave
+                double r = (double)rew;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
+                if ((threadIdx.x & 63) == 0) atomicAdd(sum, r);
+            } else {
+                atomicAdd(sum, (double)rew);
+            }
+        }
     }
     const double vx = (double)vxf, vy = (double)vyf;                                // ALAN:606-613
     const double R = p.reward_scale * (vx * d[0] + vy * d[1]) + (1.0 - p.reward_scale) * (vx * d[2] + vy * d[3]);
