@@ -211,6 +211,12 @@ constexpr int POOL_SLOTS = 16;  // LP3 pool slots per wave (lanes beyond that ta
 //     because tLeft only grows and tRight only shrinks).
 // Every lane of a group holds the same `result`; arithmetic per line is that of lp1()/lp3() above.
 // header of slot s: pool[(2 ML - 1) * POOL_SLOTS + s] = (result.x, result.y, bits(n | numObst << 8 | begin << 16), -)
+// value of the lane whose index differs in bit 0 (CTRL = 0xB1: quad_perm [1,0,3,2]) or bit 1 (0x4E: [2,3,0,1])
+template <int CTRL>
+__device__ __forceinline__ int quad_xor(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ float quad_xor(float v) { return __int_as_float(quad_xor<CTRL>(__float_as_int(v))); }
+
 __device__ __noinline__ void lp3_coop(float4* pool, int ML, int nslots, float radius) {
     const int lane = threadIdx.x & 63, slot = lane >> 2, q = lane & 3;
     float4* hdr = pool + (size_t)(2 * ML - 1) * POOL_SLOTS;
@@ -271,12 +277,19 @@ __device__ __noinline__ void lp3_coop(float4* pool, int ML, int nslots, float ra
                         tLeft = (left && tLeft < t) ? t : tLeft;
                         failed |= (par && num < 0.0f) ? 1 : 0;
                     }
-#pragma unroll
-                    for (int x = 1; x <= 2; x <<= 1) {
-                        const float oR = __shfl_xor(tRight, x), oL = __shfl_xor(tLeft, x);
+                    // merge over the group's four lanes: two quad-permute steps (lane ^ 1, then lane ^ 2) as DPP
+                    // register moves -- a ds_bpermute per value and step would sit in this serial chain instead
+                    {
+                        const float oR = quad_xor<0xB1>(tRight), oL = quad_xor<0xB1>(tLeft);
                         tRight = (oR < tRight) ? oR : tRight;
                         tLeft = (tLeft < oL) ? oL : tLeft;
-                        failed |= __shfl_xor(failed, x);
+                        failed |= quad_xor<0xB1>(failed);
+                    }
+                    {
+                        const float oR = quad_xor<0x4E>(tRight), oL = quad_xor<0x4E>(tLeft);
+                        tRight = (oR < tRight) ? oR : tRight;
+                        tLeft = (tLeft < oL) ? oL : tLeft;
+                        failed |= quad_xor<0x4E>(failed);
                     }
                     if (failed || tLeft > tRight) ok = false;  // lp2 stops here and LP3 keeps its previous result
                     else res = (dot(opt, L.dir) > 0.0f) ? L.point + tRight * L.dir : L.point + tLeft * L.dir;
