@@ -175,7 +175,7 @@ def main():
                       for k, v in kms_of.items() if kbytes_of[k] > 0}
         traffic = None
         try:  # HBM bytes per launch from this round's committed rocprofv3 --pmc passes of this command
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_z_hbm_traffic_pmc.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_final_hbm_traffic_pmc.json")))
             if args.workload == "C3" and full:
                 traffic = tj["kernels"][dom]["hbm_bytes_high"]
         except Exception:
