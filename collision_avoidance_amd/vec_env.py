@@ -72,8 +72,8 @@ class VecCollisionAvoidanceEnv:
             dev = torch.device("cuda", self.device)
             self._obs_t = torch.zeros((self.A, self.N, _lib.OBS_DIM), dtype=torch.float32, device=dev)
             self._call("ca_bind_obs", self.h, C.c_void_p(self._obs_t.data_ptr()), self._obs_t.numel() * 4)
-            self._rew_t = torch.zeros((self.A, self.N), dtype=torch.float32, device=dev)
-            self._done_t = torch.zeros((self.A,), dtype=torch.int32, device=dev)
+            self._rew_t = self.field_tensor(_lib.FLD_REWARD)        # views of the library's own buffers: no copies
+            self._done_t = self.field_tensor(_lib.FLD_ARENA_DONE)
             self._act_t = torch.zeros((self.A, self.N), dtype=torch.float32, device=dev)
         self.set_obstacles(polys)
         if scenario is not None:
@@ -126,6 +126,24 @@ class VecCollisionAvoidanceEnv:
             arr = np.transpose(np.asarray(arr, dt).reshape(self.A, self.N, self.n_actions), (0, 2, 1))
         a = np.ascontiguousarray(np.asarray(arr, dt).reshape(shape))
         self._call("ca_set", self.h, field, _ptr(a), a.nbytes, 0)
+
+    def field_tensor(self, field):
+        """Zero-copy torch view of a state field's device buffer (valid until close(); kernels of this handle run on
+        torch's current stream, so ordinary stream ordering applies)."""
+        if torch is None:
+            raise RuntimeError("field_tensor needs PyTorch")
+        shape, dt = self._shape_dtype(field)
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        self._call("ca_field_ptr", self.h, field, C.byref(ptr), C.byref(nbytes))
+
+        class _View(object):   # the CUDA array interface, which torch.as_tensor understands
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": np.dtype(dt).str, "data": (int(ptr.value), False),
+                                      "version": 2, "strides": None}
+        t = torch.as_tensor(v, device=torch.device("cuda", self.device))
+        assert t.numel() * t.element_size() == nbytes.value
+        return t
 
     def neighbor_lists(self):
         """(count [A,N], idx [A,N,K]) of the ORCA agent neighbours of the last step, nearest first."""
@@ -231,10 +249,6 @@ class VecCollisionAvoidanceEnv:
                 actions = torch.as_tensor(np.asarray(actions, np.float32).reshape(self.A, self.N))
             self._act_t.copy_(actions.reshape(self.A, self.N), non_blocking=True)
             self._call("ca_step", self.h, C.c_void_p(self._act_t.data_ptr()), flags)
-            self._call("ca_get", self.h, _lib.FLD_REWARD, C.c_void_p(self._rew_t.data_ptr()),
-                       self._rew_t.numel() * 4, 1)
-            self._call("ca_get", self.h, _lib.FLD_ARENA_DONE, C.c_void_p(self._done_t.data_ptr()),
-                       self._done_t.numel() * 4, 1)
             return (self._obs_t if with_obs else None), self._rew_t, self._done_t, {}
         a = np.ascontiguousarray(np.asarray(actions, np.float32).reshape(self.A, self.N))
         self._call("ca_step_host", self.h, _ptr(a), flags)

@@ -441,3 +441,23 @@ def test_world_without_obstacles_and_ragged_edges():
     H.assert_state_equal(g, e, "single agents", obs=True)
     H.assert_stats_equal(g, e, "single agents")
     g.close()
+
+
+def test_zero_copy_field_views():
+    """VecCollisionAvoidanceEnv hands reward / done / any field out as torch views of the library's buffers."""
+    import torch
+    from collision_avoidance_amd import _lib
+    env = H.make_gpu(12, 16, "crowd", scenarios.bench_params(16, 1.5, 5), use_torch=True)
+    env.reset()
+    act = torch.rand((12, 16), device="cuda") - 0.5
+    for s in range(10):
+        obs, rew, done, _ = env.step(act)
+    torch.cuda.synchronize()
+    assert rew.data_ptr() == env.field_tensor(_lib.FLD_REWARD).data_ptr() and rew.shape == (12, 16)
+    np.testing.assert_array_equal(rew.cpu().numpy(), env.get(_lib.FLD_REWARD))
+    np.testing.assert_array_equal(done.cpu().numpy(), env.get(_lib.FLD_ARENA_DONE))
+    g = env.field_tensor(_lib.FLD_GOAL_X)
+    assert g.dtype == torch.float64
+    np.testing.assert_array_equal(g.cpu().numpy(), env.get(_lib.FLD_GOAL_X))
+    assert obs.data_ptr() == env.field_tensor(_lib.FLD_OBS).data_ptr()      # the bound observation tensor
+    env.close()
