@@ -247,8 +247,13 @@ class VecCollisionAvoidanceEnv:
         if self.use_torch:
             if not isinstance(actions, torch.Tensor):
                 actions = torch.as_tensor(np.asarray(actions, np.float32).reshape(self.A, self.N))
-            self._act_t.copy_(actions.reshape(self.A, self.N), non_blocking=True)
-            self._call("ca_step", self.h, C.c_void_p(self._act_t.data_ptr()), flags)
+            if actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous() and \
+                    actions.numel() == self.A * self.N and actions.device.index == self.device:
+                src = actions                      # already where and what the kernel reads: no staging copy
+            else:
+                self._act_t.copy_(actions.reshape(self.A, self.N), non_blocking=True)
+                src = self._act_t
+            self._call("ca_step", self.h, C.c_void_p(src.data_ptr()), flags)
             return (self._obs_t if with_obs else None), self._rew_t, self._done_t, {}
         a = np.ascontiguousarray(np.asarray(actions, np.float32).reshape(self.A, self.N))
         self._call("ca_step_host", self.h, _ptr(a), flags)
