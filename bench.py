@@ -180,6 +180,27 @@ def main():
                 traffic = tj["kernels"][dom]["hbm_bytes_high"]
         except Exception:
             traffic = None
+        # vector-ALU view (SURVEY 8d asks for it next to the HBM fraction): wave-level VALU instructions per launch
+        # from this round's committed SQ counter pass of this command x 64 lanes, over the live kernel times,
+        # against the chip's issue peak of 256 CUs x 128 lanes x 2.4 GHz lane-instructions/s (4 SIMD-32 per CU: a
+        # wave64 instruction takes 2 cycles when two waves alternate, 4 for a wave alone; = 157 TFLOP/s for FMAs)
+        valu = None
+        try:
+            if args.workload == "C3" and full:
+                cnt, cur = {}, None
+                for line in open(os.path.join(ROOT, "profiles", "r01_final_sq_pmc.txt")):
+                    if "kernel" in line and "launches" in line:
+                        cur = "step_kernel" if "step_kernel" in line else ("obs_kernel" if "obs_kernel" in line else None)
+                    elif cur and line.split() and line.split()[0] == "SQ_INSTS_VALU":
+                        cnt[cur] = float(line.split()[1])
+                lane_ops = 64.0 * sum(cnt[k] for k in kms_of)
+                peak = 256 * 128 * 2.4e9
+                valu = {"wave_insts_per_step": {k: cnt[k] for k in kms_of}, "lane_ops_per_s": lane_ops / (sum(kms_of.values()) * 1e-3),
+                        "peak_lane_ops_per_s": peak, "frac": lane_ops / (sum(kms_of.values()) * 1e-3) / peak,
+                        "per_kernel_frac": {k: 64.0 * cnt[k] / (kms_of[k] * 1e-3) / peak for k in kms_of},
+                        "source": "profiles/r01_final_sq_pmc.txt (SQ_INSTS_VALU per launch) over the live kernel times"}
+        except Exception:
+            valu = None
         out = {
             "metric": "agent-steps/sec (whole node), %d arenas x %d agents per GPU" % (A, N),
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
@@ -194,6 +215,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_agent": kbytes, "kernel_ms": kms, "per_kernel": per_kernel},
+            "valu": valu,
             "kernels_ms": dict({k: round(v, 5) for k, v in kms_of.items()}, sum=round(sum(kms_of.values()), 5),
                                wall_per_step=dt / args.steps * 1e3),
             "full_step_algorithmic": {"bytes_per_agent": 316 if full else 52,
