@@ -355,6 +355,55 @@ def gen_alan_online():
     print("alan_online.npz: %d cases, done counts %s" % (len(cases), [int(out["c%d_done" % i][-1].sum()) for i in range(len(cases))]))
 
 
+def gen_alan_orca():
+    """ALAN_true.py run_sim(mode=0): orca_step (:631-636) + step counter + done_test (:118-121) until every agent
+    has arrived, i.e. the reference's own plain-ORCA episode loop, with its return values."""
+    import warnings
+    warnings.simplefilter("ignore")
+    import collision_avoidance.ALAN.ALAN_true as alan
+    out = {}
+    cases = (("crowd", 10), ("circle", 12), ("incoming", 10), ("congested", 8))
+    for ci, (scen, n) in enumerate(cases):
+        alan.uniform = _Stream(700 + ci)
+        sim = alan.Collision_Avoidance_Sim(numAgents=n, scenario=scen, visualize=False)
+        sim.reset(None)
+        key = "c%d_" % ci
+        out[key + "scenario"] = np.array(scen)
+        out[key + "pos0"] = np.array([sim.sim.getAgentPosition(i) for i in range(n)], np.float32)
+        out[key + "vel0"] = np.array([sim.sim.getAgentVelocity(i) for i in range(n)], np.float32)
+        out[key + "goal0"] = np.array([sim.world["targets_pos"][i][0] for i in range(n)], np.float64)
+        out[key + "goal20"] = np.array([sim.world["targets_pos"][i][1] for i in range(n)], np.float64)
+        out[key + "pref0"] = np.array([sim.sim.getAgentPrefVelocity(i) for i in range(n)], np.float32)
+        rec = dict(pos=[], vel=[], done=[])
+        steps = 0
+        cap = min(sim.max_step, 1500)
+        for s_ in range(cap):                       # the body of run_sim(0), recorded step by step
+            sim.orca_step()
+            sim.step_count += 1
+            success = sim.done_test()
+            steps += 1
+            rec["pos"].append([sim.sim.getAgentPosition(i) for i in range(n)])
+            rec["vel"].append([sim.sim.getAgentVelocity(i) for i in range(n)])
+            rec["done"].append(list(sim.agents_done))
+            if success:
+                break
+        out[key + "pos"] = np.array(rec["pos"], np.float32)[::5]       # every 5th step
+        out[key + "vel"] = np.array(rec["vel"], np.float32)[::5]
+        out[key + "pos_last"] = np.array(rec["pos"][-1], np.float32)
+        out[key + "done"] = np.array(rec["done"], np.int32)[::5]
+        out[key + "done_last"] = np.array(rec["done"][-1], np.int32)
+        out[key + "steps"] = np.int32(steps)
+        out[key + "success"] = np.int32(bool(success))
+        out[key + "agents_time"] = np.array(sim.agents_time, np.float64)
+        times = np.array(sim.agents_time)
+        out[key + "TTime"] = np.float64(np.average(times) + 3 * np.std(times, 0))
+        out[key + "max_step"] = np.int32(sim.max_step)
+    out["n_cases"] = np.int32(len(cases))
+    np.savez_compressed(os.path.join(HERE, "alan_orca.npz"), **out)
+    print("alan_orca.npz: %d cases, steps %s, success %s" % (len(cases), [int(out["c%d_steps" % i]) for i in range(len(cases))],
+                                                             [int(out["c%d_success" % i]) for i in range(len(cases))]))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
@@ -366,3 +415,4 @@ if __name__ == "__main__":
                     spawn_squeeze={(5.0, 10): (0.0, 0.25), (0, 10): (0.3, 0.7)})
     gen_alan_scenarios()
     gen_alan_online()
+    gen_alan_orca()

@@ -206,3 +206,17 @@ def test_alan_error_behaviour():
     with pytest.raises(RuntimeError, match="do not apply"):
         env._call("ca_alan_step", env.h, None, 0, _lib.F_AUTORESET)
     env.close()
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_gpu_reproduces_reference_orca_episodes(golden_dir, ci):
+    """run_sim(mode=0) of the reference (recorded in tests/golden/alan_orca.npz) through ca_orca_step."""
+    from tests.test_oracle_alan import load_orca_case, replay_orca_episode
+    c = load_orca_case(golden_dir, ci)
+
+    def make(n, scen, p):
+        return H.make_gpu(1, n, scen, p, max_obst_neighbors=8)
+    env, n, p = setup_env(make, c, lambda e, f, v: e.set(f, v), _lib)
+    env.set(_lib.FLD_PREF_X, c["pref0"][:, 0]); env.set(_lib.FLD_PREF_Y, c["pref0"][:, 1])
+    replay_orca_episode(env, c, _lib, lambda e: e.orca_step(), lambda e, f: e.get(f))
+    env.close()
