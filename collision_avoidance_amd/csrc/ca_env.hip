@@ -344,11 +344,24 @@ static void split_crossing_edges(std::vector<ObstDev>& tab) {
     }
 }
 
+// Stream discipline: a handle's own stream is hipStreamNonBlocking, i.e. NOT ordered against the legacy
+// null stream, and a fill of device memory through the blocking API is still asynchronous on the device
+// (and split into a bulk and a tail command for sizes that are not a multiple of 8 bytes).  So nothing in
+// this file touches the null stream: every fill and copy is the *Async form on the handle's stream, and
+// an entry point that hands memory to later calls finishes with hipStreamSynchronize(e->stream).
 template <class T>
-static hipError_t dalloc(T** p, size_t n) {
+static hipError_t dalloc(ca_env* e, T** p, size_t n, bool zero = true) {
     hipError_t r = hipMalloc((void**)p, n * sizeof(T));
-    if (r != hipSuccess) return r;
-    return hipMemset(*p, 0, n * sizeof(T));
+    if (r != hipSuccess || !zero) return r;
+    return hipMemsetAsync(*p, 0, n * sizeof(T), e->stream);
+}
+static hipError_t upload(ca_env* e, void* dst, const void* src, size_t bytes) {  // host -> device, complete on return
+    hipError_t r = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream);
+    return r != hipSuccess ? r : hipStreamSynchronize(e->stream);
+}
+static hipError_t download(ca_env* e, void* dst, const void* src, size_t bytes) {  // device -> host, complete on return
+    hipError_t r = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream);
+    return r != hipSuccess ? r : hipStreamSynchronize(e->stream);
 }
 
 extern "C" {
@@ -421,22 +434,22 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     const size_t an = AN(e), A = cfg->n_arenas;
     float** f32s[] = {&e->pos_x, &e->pos_y, &e->vel_x, &e->vel_y, &e->pref_x, &e->pref_y, &e->reward,
                       &e->tmp_x, &e->tmp_y, &e->orient_x, &e->orient_y};
-    for (auto p : f32s) if (r == hipSuccess) r = dalloc(p, an);
+    for (auto p : f32s) if (r == hipSuccess) r = dalloc(e, p, an);
     double** f64s[] = {&e->goal_x, &e->goal_y, &e->goal2_x, &e->goal2_y};
-    for (auto p : f64s) if (r == hipSuccess) r = dalloc(p, an);
+    for (auto p : f64s) if (r == hipSuccess) r = dalloc(e, p, an);
     int** i32s[] = {&e->agent_done, &e->arrive_step, &e->regoal_count, &e->nb_count, &e->obst_count};
-    for (auto p : i32s) if (r == hipSuccess) r = dalloc(p, an);
-    if (r == hipSuccess) r = dalloc(&e->nb_idx, an * (size_t)(e->K > 0 ? e->K : 1));
-    if (r == hipSuccess) r = dalloc(&e->obst_idx, an * (size_t)e->S);
-    if (r == hipSuccess) r = dalloc(&e->step_count, A);
-    if (r == hipSuccess) r = dalloc(&e->arena_done, A);
-    if (r == hipSuccess) r = dalloc(&e->episode, A);
-    if (r == hipSuccess) r = dalloc(&e->arena_stats, A * ST_STRIDE);
-    if (r == hipSuccess) r = dalloc(&e->obs, an * CA_OBS_DIM);
-    if (r == hipSuccess) r = dalloc(&e->d_obst, (size_t)1);
+    for (auto p : i32s) if (r == hipSuccess) r = dalloc(e, p, an);
+    if (r == hipSuccess) r = dalloc(e, &e->nb_idx, an * (size_t)(e->K > 0 ? e->K : 1));
+    if (r == hipSuccess) r = dalloc(e, &e->obst_idx, an * (size_t)e->S);
+    if (r == hipSuccess) r = dalloc(e, &e->step_count, A);
+    if (r == hipSuccess) r = dalloc(e, &e->arena_done, A);
+    if (r == hipSuccess) r = dalloc(e, &e->episode, A);
+    if (r == hipSuccess) r = dalloc(e, &e->arena_stats, A * ST_STRIDE);
+    if (r == hipSuccess) r = dalloc(e, &e->obs, an * CA_OBS_DIM);
+    if (r == hipSuccess) r = dalloc(e, &e->d_obst, (size_t)1);
 #ifdef CA_STAMPS
-    if (r == hipSuccess) r = dalloc(&e->dbg, (size_t)std::max(e->grid * (e->BS / 64), e->grid_n * (e->BSn / 64)) * 16);
-    if (r == hipSuccess) r = dalloc(&e->dbg_obs, (size_t)cfg->n_arenas * ((cfg->n_agents + 15) / 16 + 16) * 4 * 16);
+    if (r == hipSuccess) r = dalloc(e, &e->dbg, (size_t)std::max(e->grid * (e->BS / 64), e->grid_n * (e->BSn / 64)) * 16);
+    if (r == hipSuccess) r = dalloc(e, &e->dbg_obs, (size_t)cfg->n_arenas * ((cfg->n_agents + 15) / 16 + 16) * 4 * 16);
 #endif
     if (r == hipSuccess && e->lds > 48 * 1024) {
         if (e->ST > 0) r = e->KT == 5 ? set_lds_attr_k<5, 4>(e->BS, e->lds) : set_lds_attr_k<10, 4>(e->BS, e->lds);
@@ -454,6 +467,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
             r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ol);
         }
     }
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);  // the zero fills are done before the handle is handed out
     if (r != hipSuccess) {
         fail(nullptr, CA_EHIP, "ca_create: %s", hipGetErrorString(r));
         ca_destroy(e);
@@ -527,8 +541,7 @@ int ca_set_obstacles(ca_env* e, const float* verts_xy, const int32_t* poly_sizes
     if (e->d_obst) HIPCHK(e, hipFree(e->d_obst));
     e->d_obst = nullptr;
     HIPCHK(e, hipMalloc((void**)&e->d_obst, (tab.size() + 1) * sizeof(ObstDev)));
-    if (!tab.empty())
-        HIPCHK(e, hipMemcpy(e->d_obst, tab.data(), tab.size() * sizeof(ObstDev), hipMemcpyHostToDevice));
+    if (!tab.empty()) HIPCHK(e, upload(e, e->d_obst, tab.data(), tab.size() * sizeof(ObstDev)));
     e->h_obst.swap(tab);
     return CA_OK;
 }
@@ -634,18 +647,19 @@ int ca_init_scenario(ca_env* e, int32_t scenario) {
         {e->vel_y, &vy}, {e->pref_x, &fx}, {e->pref_y, &fy}};
     struct { double* d; std::vector<double>* h; } upd[] = {{e->goal_x, &gx}, {e->goal_y, &gy},
         {e->goal2_x, &g2x}, {e->goal2_y, &g2y}};
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    for (auto& u : up) HIPCHK(e, hipMemcpy(u.d, u.h->data(), an * 4, hipMemcpyHostToDevice));
-    for (auto& u : upd) HIPCHK(e, hipMemcpy(u.d, u.h->data(), an * 8, hipMemcpyHostToDevice));
-    HIPCHK(e, hipMemset(e->agent_done, 0, an * 4));
-    HIPCHK(e, hipMemset(e->arrive_step, 0xff, an * 4));
-    HIPCHK(e, hipMemset(e->regoal_count, 0, an * 4));
-    HIPCHK(e, hipMemset(e->nb_count, 0, an * 4));
-    HIPCHK(e, hipMemset(e->obst_count, 0, an * 4));
-    HIPCHK(e, hipMemset(e->step_count, 0, (size_t)A * 4));
-    HIPCHK(e, hipMemset(e->arena_done, 0, (size_t)A * 4));
-    HIPCHK(e, hipMemset(e->episode, 0, (size_t)A * 4));
-    HIPCHK(e, hipMemset(e->obs, 0, an * CA_OBS_DIM * 4));
+    hipStream_t st = e->stream;  // everything below is ordered on the handle's stream (see dalloc)
+    for (auto& u : up) HIPCHK(e, hipMemcpyAsync(u.d, u.h->data(), an * 4, hipMemcpyHostToDevice, st));
+    for (auto& u : upd) HIPCHK(e, hipMemcpyAsync(u.d, u.h->data(), an * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemsetAsync(e->agent_done, 0, an * 4, st));
+    HIPCHK(e, hipMemsetAsync(e->arrive_step, 0xff, an * 4, st));
+    HIPCHK(e, hipMemsetAsync(e->regoal_count, 0, an * 4, st));
+    HIPCHK(e, hipMemsetAsync(e->nb_count, 0, an * 4, st));
+    HIPCHK(e, hipMemsetAsync(e->obst_count, 0, an * 4, st));
+    HIPCHK(e, hipMemsetAsync(e->step_count, 0, (size_t)A * 4, st));
+    HIPCHK(e, hipMemsetAsync(e->arena_done, 0, (size_t)A * 4, st));
+    HIPCHK(e, hipMemsetAsync(e->episode, 0, (size_t)A * 4, st));
+    HIPCHK(e, hipMemsetAsync(e->obs, 0, an * CA_OBS_DIM * 4, st));
+    HIPCHK(e, hipStreamSynchronize(st));  // the host vectors above go out of scope
     e->orient_valid = false;
     return CA_OK;
 }
@@ -730,9 +744,8 @@ int ca_reset_masked(ca_env* e, const int32_t* mask, int32_t mask_is_device, uint
     HIPCHK(e, hipSetDevice(e->device));
     const int A = e->cfg.n_arenas;
     if (!mask_is_device) {
-        if (!e->mask_buf) HIPCHK(e, dalloc(&e->mask_buf, (size_t)A));
-        HIPCHK(e, hipMemcpyAsync(e->mask_buf, mask, (size_t)A * 4, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (!e->mask_buf) HIPCHK(e, dalloc(e, &e->mask_buf, (size_t)A, /*zero=*/false));  // fully overwritten below
+        HIPCHK(e, upload(e, e->mask_buf, mask, (size_t)A * 4));
         mask = e->mask_buf;
     }
     StepArgs a;
@@ -798,11 +811,12 @@ int ca_alan_configure(ca_env* e, const double* actions_xy, int32_t n_actions, do
     if (e->alan_action) { hipFree(e->alan_action); e->alan_action = nullptr; }
     e->n_actions = 0;
     const size_t an = AN(e);
-    HIPCHK(e, dalloc(&e->alan_w, an * (size_t)n_actions));
-    HIPCHK(e, dalloc(&e->alan_t, an * (size_t)n_actions));
-    HIPCHK(e, dalloc(&e->alan_dirs, an * 4));
-    HIPCHK(e, dalloc(&e->alan_u, an));
-    HIPCHK(e, dalloc(&e->alan_action, an));
+    HIPCHK(e, dalloc(e, &e->alan_w, an * (size_t)n_actions));
+    HIPCHK(e, dalloc(e, &e->alan_t, an * (size_t)n_actions));
+    HIPCHK(e, dalloc(e, &e->alan_dirs, an * 4));
+    HIPCHK(e, dalloc(e, &e->alan_u, an));
+    HIPCHK(e, dalloc(e, &e->alan_action, an));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
     for (int k = 0; k < n_actions; ++k) {  // (cos, sin) of atan2(y, x) = the normalised vector (ALAN:592-595)
         const double x = actions_xy[2 * k], y = actions_xy[2 * k + 1], len = std::sqrt(x * x + y * y);
         e->act_c[k] = len == 0.0 ? 1.0 : x / len;
@@ -928,11 +942,10 @@ int ca_debug_math(ca_env* e, int32_t op, const void* in, void* out, int32_t n) {
     void *di = nullptr, *dout = nullptr;
     HIPCHK(e, hipMalloc(&di, in_b[op] * n));
     HIPCHK(e, hipMalloc(&dout, out_b[op] * n));
-    HIPCHK(e, hipMemcpy(di, in, in_b[op] * n, hipMemcpyHostToDevice));
+    HIPCHK(e, upload(e, di, in, in_b[op] * n));
     hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, op, di, dout, n, e->cfg.seed);
     HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    HIPCHK(e, hipMemcpy(out, dout, out_b[op] * n, hipMemcpyDeviceToHost));
+    HIPCHK(e, download(e, out, dout, out_b[op] * n));
     hipFree(di);
     hipFree(dout);
     return CA_OK;
@@ -948,8 +961,7 @@ int ca_debug_stamps(ca_env* e, unsigned long long* out, int32_t max_waves, int32
     if (n_waves) *n_waves = nw;
     const int n = nw < max_waves ? nw : max_waves;
     HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    HIPCHK(e, hipMemcpy(out, obs ? e->dbg_obs : e->dbg, (size_t)n * 16 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(e, download(e, out, obs ? e->dbg_obs : e->dbg, (size_t)n * 16 * 8));
     return CA_OK;
 }
 

@@ -199,6 +199,18 @@ class VecCollisionAvoidanceEnv:
         return dict(block=v[0].value, grid=v[1].value, lds_bytes=v[2].value, obs_grid=v[3].value)
 
     # ---- the environment API ----------------------------------------------------------------------
+    def _on_device(self, t, dtype):
+        """A torch tensor as (contiguous tensor on this handle's GPU, True) or, for a CPU tensor, as
+        (numpy array, False): the library dereferences a device pointer as device memory, so a CPU tensor
+        must take the host path and a tensor of another GPU is moved here first."""
+        if not t.is_cuda:
+            return t.detach().to(dtype=dtype).contiguous().numpy(), False
+        dev = torch.device("cuda", self.device)
+        t = t.detach().to(device=dev, dtype=dtype).contiguous()
+        if not self.use_torch:   # the handle runs on a stream of its own: torch's producer must be finished
+            torch.cuda.current_stream(self.device).synchronize()
+        return t, True
+
     def _obs_out(self):
         return self._obs_t if self.use_torch else self.get(_lib.FLD_OBS)
 
@@ -208,12 +220,19 @@ class VecCollisionAvoidanceEnv:
         flags = _lib.F_OBS if with_obs else 0
         if pos_x is None:
             self._call("ca_reset", self.h, None, None, 0, flags)
-        elif torch is not None and isinstance(pos_x, torch.Tensor):
-            px = pos_x.to(dtype=torch.float32).contiguous()
-            py = pos_y.to(dtype=torch.float32).contiguous()
+        elif torch is not None and isinstance(pos_x, torch.Tensor) and pos_x.is_cuda and \
+                isinstance(pos_y, torch.Tensor) and pos_y.is_cuda:
+            px, _ = self._on_device(pos_x, torch.float32)
+            py, _ = self._on_device(pos_y, torch.float32)
+            if px.numel() != self.A * self.N or py.numel() != self.A * self.N:
+                raise ValueError("reset: pos_x / pos_y must hold %d x %d values" % (self.A, self.N))
             self._call("ca_reset", self.h, C.c_void_p(px.data_ptr()), C.c_void_p(py.data_ptr()), 1, flags)
             self.sync()
         else:
+            if torch is not None and isinstance(pos_x, torch.Tensor):
+                pos_x = pos_x.detach().cpu().numpy()
+            if torch is not None and isinstance(pos_y, torch.Tensor):
+                pos_y = pos_y.detach().cpu().numpy()
             px = np.ascontiguousarray(np.asarray(pos_x, np.float32).reshape(self.A, self.N))
             py = np.ascontiguousarray(np.asarray(pos_y, np.float32).reshape(self.A, self.N))
             self._call("ca_reset", self.h, _ptr(px), _ptr(py), 0, flags)
@@ -222,9 +241,13 @@ class VecCollisionAvoidanceEnv:
     def reset_masked(self, mask, with_obs=True):
         """reset() for the arenas with mask[a] != 0 only (numpy or device int32 tensor [A])."""
         flags = _lib.F_OBS if with_obs else 0
+        on_dev = False
         if torch is not None and isinstance(mask, torch.Tensor):
-            m = mask.to(dtype=torch.int32).contiguous()
-            self._call("ca_reset_masked", self.h, C.c_void_p(m.data_ptr()), 1, flags)
+            mask, on_dev = self._on_device(mask, torch.int32)
+        if on_dev:
+            if mask.numel() != self.A:
+                raise ValueError("reset_masked: mask must hold %d values" % self.A)
+            self._call("ca_reset_masked", self.h, C.c_void_p(mask.data_ptr()), 1, flags)
             self.sync()
         else:
             m = np.ascontiguousarray(np.asarray(mask, np.int32).reshape(self.A))
@@ -294,11 +317,15 @@ class VecCollisionAvoidanceEnv:
         flags = (_lib.F_OBS if with_obs else 0) | (_lib.F_STATS if stats else 0) | (_lib.F_FREEZE if freeze else 0)
         if u is None:
             self._call("ca_alan_step", self.h, None, 0, flags)
-        elif torch is not None and isinstance(u, torch.Tensor):
-            ud = u.to(dtype=torch.float64).contiguous()
+        elif torch is not None and isinstance(u, torch.Tensor) and u.is_cuda:
+            ud, _ = self._on_device(u, torch.float64)
+            if ud.numel() != self.A * self.N:
+                raise ValueError("alan_step: u must hold %d x %d values" % (self.A, self.N))
             self._call("ca_alan_step", self.h, C.c_void_p(ud.data_ptr()), 1, flags)
             self.sync()
         else:
+            if torch is not None and isinstance(u, torch.Tensor):
+                u = u.detach().numpy()
             uh = np.ascontiguousarray(np.asarray(u, np.float64).reshape(self.A, self.N))
             self._call("ca_alan_step", self.h, _ptr(uh), 0, flags)
         return self._obs_out() if with_obs else None
