@@ -8,13 +8,18 @@ GPU (BASELINE.json configs[2], "C3": random start/goal crowd, neighborDist 5, ma
 state and actions resident in HBM.  value = agents advanced per second over all GPUs.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2|C5] [--mode step|orca]
-                  [--no-cpu-baseline]
-N > 1: launched by torch.distributed.run, one rank per GPU; arenas are sharded (no data-path
-collective: arenas never interact), one RCCL all_gather of the per-rank statistics at the end.
+                  [--variant walls|free] [--starts overlap|separated] [--no-cpu-baseline]
+
+N > 1: one rank per GPU (torch.distributed.run; when this script is started directly with --gpus N it
+starts the N ranks itself, as a child process, before anything touches the GPU, and relays rank 0's line);
+arenas are sharded (no data-path collective: arenas never interact), ONE RCCL all_gather of the per-rank
+statistics at the end.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,32 +27,59 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+VALU_PEAK_LANE_OPS = 256 * 128 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions/s (= 157 TFLOP/s for FMAs)
 # algorithmic bytes per agent-step
 BYTES_STEP_KERNEL_FULL = 60   # read pos 8 vel 8 goal 8 done 4 action 4; write pos 8 vel 8 done 4 stat 4 reward 4
 BYTES_STEP_KERNEL_ORCA = 52
 BYTES_OBS_KERNEL = 256        # the 64-float observation row
+MIN_WARM_SECONDS = 1.0        # clocks settle: the warm-up runs at least this long whatever --warmup says
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C5"])
     ap.add_argument("--mode", default="step", choices=["step", "orca"])
+    ap.add_argument("--variant", default="walls", choices=["walls", "free"],
+                    help="SURVEY 8d: A = with the boundary polygon (default), B = obstacle-free")
+    ap.add_argument("--starts", default="overlap", choices=["overlap", "separated"],
+                    help="SURVEY 8d: uniform starts (overlaps allowed, default) or rejection-sampled non-overlapping starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def cpu_baseline(workload, mode, seconds):
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks with torch.distributed.run as a CHILD
+    process (nothing in this process has touched the GPU), relay its output and exit with its code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if r.returncode != 0 or line is None:
+        sys.stdout.write(r.stdout)
+        raise SystemExit(r.returncode or 1)
+    print(line)
+    raise SystemExit(0)
+
+
+def cpu_baseline(workload, mode, seconds, variant="walls", starts="overlap"):
     """The CPU oracle (a C++ restatement of the same path) on a bounded sample of the same workload: arenas of the
     same scenario stepped for about `seconds`, first on one core, then on all cores of this process's share of
     the host (arenas dealt to threads).  `value` is the multi-core rate, `cores` the threads used."""
+    import numpy as np
     from collision_avoidance_amd import scenarios
     from oracle import oracle as o
     from tests import helpers as H
@@ -58,10 +90,11 @@ def cpu_baseline(workload, mode, seconds):
     except Exception:
         cores = max(1, min(32, os.cpu_count() or 1))
     rng = np.random.RandomState(0)
+    scn = "crowd" if starts == "overlap" else "crowd_separated"
 
     def run(A, threads, budget):
         p = scenarios.bench_params(N, w["neighbor_dist"], w["max_neighbors"])
-        env = H.make_oracle(A, N, "crowd", p, seed=0)
+        env = H.make_oracle(A, N, scn, p, seed=0, polys=None if variant == "walls" else [])
         acts = rng.uniform(-0.5, 0.5, (8, A, N)).astype(np.float32)
         flags = o.F_OBS if mode == "step" else 0
         for s in range(3):
@@ -81,15 +114,43 @@ def cpu_baseline(workload, mode, seconds):
     vm, sm, dm = run(Am, cores, seconds * 0.6)
     return {"value": vm, "unit": "agent-steps/s", "cores": cores, "kind": "port", "single_core_value": v1,
             "sample": "%d arenas x %d agents x %d steps on %d threads (%.1f s) and %d arenas x %d steps on one (%.1f s), "
-                      "same workload (%s mode), oracle/ca_oracle.cpp -O2" % (Am, N, sm, cores, dm, A1, s1, d1, mode)}
+                      "same workload (%s mode, %s, %s starts), oracle/ca_oracle.cpp -O2"
+                      % (Am, N, sm, cores, dm, A1, s1, d1, mode, variant, starts)}
+
+
+def counters_for(workload, mode, variant, starts, kernels):
+    """HBM traffic (FETCH_SIZE / WRITE_SIZE passes) and SQ_INSTS_VALU of this command from the newest committed
+    rocprofv3 --pmc summary (profiles/*_counters_<workload>_<mode>.json, written by tools/counters.py) -- quoted
+    ONLY if that summary was taken from the kernel sources the loaded library was built from (source hash match);
+    otherwise null with the reason, so a changed kernel can never carry stale counter data."""
+    import glob
+    from collision_avoidance_amd import build as _b
+    sha = _b.source_sha()
+    tag = "%s_%s" % (workload, mode) + ("" if variant == "walls" else "_free") + ("" if starts == "overlap" else "_separated")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters_%s.json" % tag)))
+    if not files:
+        return None, "no counter profile committed for %s" % tag
+    for f in reversed(files):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        if j.get("src_sha") == sha:
+            return j, os.path.relpath(f, ROOT)
+    return None, "newest counter profile (%s) was taken from other kernel sources than this build (%s)" % (
+        os.path.basename(files[-1]), sha)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
+    import numpy as np  # noqa: F401
+    import torch
     from collision_avoidance_amd import dist as cad
     rank, world, local = cad.rank_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     # rehearsal switches (not used by the driver): CA_BENCH_BACKEND=gloo lets several ranks share one
     # GPU on a 1-GPU box; the production path is one rank per GPU over RCCL ("nccl").
     backend = os.environ.get("CA_BENCH_BACKEND", "nccl")
@@ -118,8 +179,10 @@ def main():
     A, N = w["n_arenas"], w["n_agents"]
     p = scenarios.bench_params(N, w["neighbor_dist"], w["max_neighbors"])
     arena_offset, _ = cad.weak_shard(A, rank)  # weak scaling: every GPU owns A arenas of the global range
-    env = VecCollisionAvoidanceEnv(A, N, scenario="crowd", params=p, device=local, seed=0,
-                                   arena_offset=arena_offset, use_torch=True)
+    scn = "crowd" if args.starts == "overlap" else "crowd_separated"
+    env = VecCollisionAvoidanceEnv(A, N, scenario=scn, params=p, device=local, seed=0,
+                                   arena_offset=arena_offset, use_torch=True,
+                                   obstacles="scenario" if args.variant == "walls" else [])
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     pool = (torch.rand((16, A, N), device="cuda", generator=gen) - 0.5)  # actions in [-0.5, 0.5] rad
     full = args.mode == "step"
@@ -130,8 +193,19 @@ def main():
         else:
             env._call("ca_orca_step", env.h, _lib.F_STATS)
 
+    # warm-up: W steps, and on until MIN_WARM_SECONDS have passed (a 5-step warm-up leaves the clocks cold:
+    # round 1's driver run read 84 us per kernel where a settled chip reads 78)
+    tw = time.perf_counter()
     for i in range(args.warmup):
         one_step(i)
+    torch.cuda.synchronize()
+    warm_run = args.warmup
+    while time.perf_counter() - tw < MIN_WARM_SECONDS:
+        for i in range(50):
+            one_step(warm_run + i)
+        warm_run += 50
+        torch.cuda.synchronize()
+    env.reset_stats()
     # the kernel launches of every 8th step of the timed region are bracketed by HIP events on the
     # stream they run on (recorded inside the library, which is where the launches are issued);
     # sampling keeps the event records from stretching the timed region (every launch: +5 % wall)
@@ -142,7 +216,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        one_step(args.warmup + i)
+        one_step(warm_run + i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -156,75 +230,78 @@ def main():
     env.profile(0)
     st = env.stats()
 
-    # the single collective of the job: per-rank statistics (RCCL all_gather over xGMI when N > 1)
-    per_rank_stats, total_stats = cad.gather_stats(st, device=coll_dev)
+    # the single data collective of the job: per-rank statistics (RCCL all_gather over xGMI when N > 1)
+    per_rank_stats, total_stats = cad.gather_stats(st, device=coll_dev, extra={"device": local})
     if rank == 0:
         agents = A * N
         value = world * agents * args.steps / dt
         kbytes_of = {"nbr_kernel": 0, "step_kernel": BYTES_STEP_KERNEL_FULL if full else BYTES_STEP_KERNEL_ORCA,
                      "obs_kernel": BYTES_OBS_KERNEL}
         kms_of = {k: v[1] for k, v in ktimes.items() if v[0] > 0 and k in kbytes_of}
-        # dominant kernel: the longest average launch among the kernels that own algorithmic HBM bytes
-        # (nbr_kernel has none); launches within 3 % of the longest count as a tie, decided by the bytes moved
-        longest = max(v for k, v in kms_of.items() if kbytes_of[k] > 0)
-        dom = max((k for k in kms_of if kbytes_of[k] > 0 and kms_of[k] >= 0.97 * longest), key=lambda k: kbytes_of[k])
+        # dominant kernel: strictly the longest average launch (no tie-break)
+        dom = max(kms_of, key=lambda k: kms_of[k])
         kms, kbytes = kms_of[dom], kbytes_of[dom]
         achieved = agents * kbytes / (kms * 1e-3) / 1e9
-        per_kernel = {k: {"algorithmic_GB_per_s": agents * kbytes_of[k] / (v * 1e-3) / 1e9,
+        per_kernel = {k: {"ms": round(v, 5), "algorithmic_bytes_per_agent": kbytes_of[k],
+                          "algorithmic_GB_per_s": agents * kbytes_of[k] / (v * 1e-3) / 1e9,
                           "frac": agents * kbytes_of[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                      for k, v in kms_of.items() if kbytes_of[k] > 0}
-        traffic = None
-        try:  # HBM bytes per launch from this round's committed rocprofv3 --pmc passes of this command
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_final_hbm_traffic_pmc.json")))
-            if args.workload == "C3" and full:
-                traffic = tj["kernels"][dom]["hbm_bytes_high"]
-        except Exception:
-            traffic = None
-        # vector-ALU view (SURVEY 8d asks for it next to the HBM fraction): wave-level VALU instructions per launch
-        # from this round's committed SQ counter pass of this command x 64 lanes, over the live kernel times,
-        # against the chip's issue peak of 256 CUs x 128 lanes x 2.4 GHz lane-instructions/s (4 SIMD-32 per CU: a
-        # wave64 instruction takes 2 cycles when two waves alternate, 4 for a wave alone; = 157 TFLOP/s for FMAs)
-        valu = None
-        try:
-            if args.workload == "C3" and full:
-                cnt, cur = {}, None
-                for line in open(os.path.join(ROOT, "profiles", "r01_final_sq_pmc.txt")):
-                    if "kernel" in line and "launches" in line:
-                        cur = "step_kernel" if "step_kernel" in line else ("obs_kernel" if "obs_kernel" in line else None)
-                    elif cur and line.split() and line.split()[0] == "SQ_INSTS_VALU":
-                        cnt[cur] = float(line.split()[1])
-                lane_ops = 64.0 * sum(cnt[k] for k in kms_of)
-                peak = 256 * 128 * 2.4e9
-                valu = {"wave_insts_per_step": {k: cnt[k] for k in kms_of}, "lane_ops_per_s": lane_ops / (sum(kms_of.values()) * 1e-3),
-                        "peak_lane_ops_per_s": peak, "frac": lane_ops / (sum(kms_of.values()) * 1e-3) / peak,
-                        "per_kernel_frac": {k: 64.0 * cnt[k] / (kms_of[k] * 1e-3) / peak for k in kms_of},
-                        "source": "profiles/r01_final_sq_pmc.txt (SQ_INSTS_VALU per launch) over the live kernel times"}
-        except Exception:
-            valu = None
+                      for k, v in kms_of.items()}
+        cj, csrc = counters_for(args.workload, args.mode, args.variant, args.starts, kms_of)
+        traffic, traffic_detail, valu = None, {"source": csrc}, None
+        if cj is not None:
+            kk = cj.get("kernels", {})
+            if dom in kk and "hbm_bytes_high" in kk[dom]:
+                traffic = kk[dom]["hbm_bytes_high"]
+            traffic_detail = {"source": csrc, "src_sha": cj.get("src_sha"),
+                              "per_kernel": {k: {x: kk[k].get(x) for x in ("FETCH_SIZE_KB", "WRITE_SIZE_KB", "hbm_bytes_low",
+                                                                           "hbm_bytes_high", "algorithmic_bytes")}
+                                             for k in kms_of if k in kk}}
+            try:  # vector-ALU view: wave-level VALU instructions per launch x 64 lanes over the live kernel times
+                cnt = {k: float(kk[k]["SQ_INSTS_VALU"]) for k in kms_of}
+                lane_ops = 64.0 * sum(cnt.values())
+                tsum = sum(kms_of.values()) * 1e-3
+                valu = {"wave_insts_per_step": cnt, "lane_ops_per_s": lane_ops / tsum,
+                        "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "frac": lane_ops / tsum / VALU_PEAK_LANE_OPS,
+                        "per_kernel_frac": {k: 64.0 * cnt[k] / (kms_of[k] * 1e-3) / VALU_PEAK_LANE_OPS for k in kms_of},
+                        "source": "%s (SQ_INSTS_VALU per launch, same kernel sources) over the live kernel times" % csrc}
+            except Exception:
+                valu = None
         out = {
             "metric": "agent-steps/sec (whole node), %d arenas x %d agents per GPU" % (A, N),
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "warmup_steps_run": warm_run, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d arenas x %d agents per GPU, random start/goal crowd (ALAN recipe), "
-                                   "neighborDist %.1f, maxNeighbors %d, %s" %
+                                   "neighborDist %.1f, maxNeighbors %d, %s, %s, %s starts" %
                                    (args.workload, A, N, w["neighbor_dist"], w["max_neighbors"],
                                     "full env step (action -> ORCA -> reward/done -> laser obs)" if full
-                                    else "ORCA-only step (no observation)"),
-                       "mode": args.mode, "sharding": "arenas, %d per GPU" % A},
+                                    else "ORCA-only step (no observation)",
+                                    "boundary walls" if args.variant == "walls" else "obstacle-free", args.starts),
+                       "mode": args.mode, "variant": args.variant, "starts": args.starts,
+                       "sharding": "arenas, %d per GPU" % A},
+            "world_size": world,
+            "ranks": [{"rank": r, "device": d["device"], "agent_steps": d["agent_steps"]}
+                      for r, d in enumerate(per_rank_stats)],
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_agent": kbytes, "kernel_ms": kms, "per_kernel": per_kernel},
+                         "algorithmic_bytes_per_agent": kbytes, "kernel_ms": kms, "per_kernel": per_kernel,
+                         "traffic_detail": traffic_detail},
             "valu": valu,
             "kernels_ms": dict({k: round(v, 5) for k, v in kms_of.items()}, sum=round(sum(kms_of.values()), 5),
                                wall_per_step=dt / args.steps * 1e3),
             "full_step_algorithmic": {"bytes_per_agent": 316 if full else 52,
-                                      "GB_per_s": agents * (316 if full else 52) / (dt / args.steps) / 1e9},
+                                      "GB_per_s": agents * (316 if full else 52) / (dt / args.steps) / 1e9,
+                                      "frac": agents * (316 if full else 52) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
             "stats": {k: total_stats[k] for k in cad.STAT_KEYS},
             "launch": env.launch_info(),
+            "src_sha": _b.source_sha(),
         }
+        if sum(d["agent_steps"] for d in per_rank_stats) != world * agents * args.steps:
+            raise SystemExit("bench.py: the ranks report %d agent-steps, expected %d" %
+                             (sum(d["agent_steps"] for d in per_rank_stats), world * agents * args.steps))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.mode, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.mode, args.cpu_seconds, args.variant, args.starts)
         print(json.dumps(out))
     env.close()
     if dist is not None:

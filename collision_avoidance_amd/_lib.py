@@ -12,7 +12,7 @@ OBS_DIM = 64
 MAX_NEIGHBORS, MAX_OBST_NEIGHBORS, MAX_AGENTS = 16, 8, 1024
 DONE_XLESS, DONE_GOAL, DONE_REGOAL = 0, 1, 2
 F_OBS, F_STATS, F_AUTORESET, F_NODONE, F_FREEZE = 1, 2, 4, 8, 16
-SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN_DEADLOCK = range(7)
+SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN_DEADLOCK, SCN_CROWD_SEPARATED = range(8)
 
 (FLD_POS_X, FLD_POS_Y, FLD_VEL_X, FLD_VEL_Y, FLD_PREF_X, FLD_PREF_Y, FLD_GOAL_X, FLD_GOAL_Y,
  FLD_GOAL2_X, FLD_GOAL2_Y, FLD_REWARD, FLD_AGENT_DONE, FLD_ARRIVE_STEP, FLD_NB_COUNT, FLD_NB_IDX,

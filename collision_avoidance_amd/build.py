@@ -13,6 +13,17 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-Wno-unused-value"]
 
 
+def source_sha():
+    """Hash of the kernel sources: profiles record it, and bench.py only quotes a counter profile whose hash is
+    that of the sources the loaded library was built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

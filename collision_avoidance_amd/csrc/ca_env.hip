@@ -560,7 +560,8 @@ int ca_get_obstacles(ca_env* e, float* verts_xy, int32_t* next, int32_t* convex,
 
 int ca_init_scenario(ca_env* e, int32_t scenario) {
     if (!e) return CA_EINVAL;
-    if (scenario < 0 || scenario > 6) return fail(e, CA_EINVAL, "ca_init_scenario: unknown scenario %d", scenario);
+    if (scenario < 0 || scenario > CA_SCN_CROWD_SEPARATED)
+        return fail(e, CA_EINVAL, "ca_init_scenario: unknown scenario %d", scenario);
     const ca_config& c = e->cfg;
     const int A = c.n_arenas, N = c.n_agents;
     const size_t an = AN(e);
@@ -576,10 +577,20 @@ int ca_init_scenario(ca_env* e, int32_t scenario) {
             rng2(c.seed, g, i, RNG_HEADING, 0, &u0, &u1);
             sincos64(uniform64(0.0, 2.0 * M_PI, u0), &s, &cs);  // env.py:89-90 / ALAN:276-277
             vx[q] = (float)cs; vy[q] = (float)s;
-            if (scenario == CA_SCN_CROWD) {  // ALAN:270-283
+            if (scenario == CA_SCN_CROWD || scenario == CA_SCN_CROWD_SEPARATED) {  // ALAN:270-283
                 const double E = std::sqrt(2.0 * r * N) * 2.0;
-                rng2(c.seed, g, i, RNG_POS, 0, &u0, &u1);
-                px[q] = (float)uniform64(0.0, E, u0); py[q] = (float)uniform64(0.0, E, u1);
+                // SURVEY 8d "rejection-sampled non-overlapping variant": the draw is repeated (sequence number
+                // 1, 2, ...) until the start keeps 2 r from the starts of the agents before it; 64 tries at most
+                const int tries = scenario == CA_SCN_CROWD_SEPARATED ? 64 : 1;
+                const float minSq = sqr(c.radius + c.radius);
+                for (int t = 0; t < tries; ++t) {
+                    rng2(c.seed, g, i, RNG_POS, (uint32_t)t, &u0, &u1);
+                    px[q] = (float)uniform64(0.0, E, u0); py[q] = (float)uniform64(0.0, E, u1);
+                    bool clear = true;
+                    for (int j = 0; j < i && clear; ++j)
+                        clear = !(absSq(mk(px[q], py[q]) - mk(px[q - i + j], py[q - i + j])) < minSq);
+                    if (clear) break;
+                }
                 rng2(c.seed, g, i, RNG_GOAL, 0, &u0, &u1);
                 gx[q] = uniform64(0.0, E, u0); gy[q] = uniform64(0.0, E, u1);
                 g2x[q] = gx[q]; g2y[q] = gy[q];

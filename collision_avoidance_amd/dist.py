@@ -32,26 +32,32 @@ def weak_shard(n_per_rank, rank):
     return rank * n_per_rank, n_per_rank
 
 
-def gather_stats(stats, device=None, group=None):
-    """all_gather of the integer statistics (+ sum_reward) of every rank; returns the per-rank list
-    and the job totals.  Works without an initialised process group (single process)."""
+def gather_stats(stats, device=None, group=None, extra=None):
+    """THE collective of a job: one all_gather of a fixed per-rank record -- the integer statistics, the bits of
+    the fp64 sum_reward and any `extra` integers (e.g. the device a rank ran on) -- returns the per-rank list and
+    the job totals.  Works without an initialised process group (single process)."""
+    import struct
     import torch
     import torch.distributed as dist
-    ints = torch.tensor([int(stats[k]) for k in STAT_KEYS], dtype=torch.int64, device=device)
-    rew = torch.tensor([float(stats.get("sum_reward", 0.0))], dtype=torch.float64, device=device)
+    extra = dict(extra or {})
+    rew_bits = struct.unpack("<q", struct.pack("<d", float(stats.get("sum_reward", 0.0))))[0]
+    rec = torch.tensor([int(stats[k]) for k in STAT_KEYS] + [rew_bits] + [int(v) for v in extra.values()],
+                       dtype=torch.int64, device=device)
     if not (dist.is_available() and dist.is_initialized()):
-        per_rank = [dict(stats)]
+        rows = [rec.tolist()]
     else:
         world = dist.get_world_size(group)
-        gi = [torch.zeros_like(ints) for _ in range(world)]
-        gr = [torch.zeros_like(rew) for _ in range(world)]
-        dist.all_gather(gi, ints, group=group)
-        dist.all_gather(gr, rew, group=group)
-        per_rank = []
-        for a, b in zip(gi, gr):
-            d = dict(zip(STAT_KEYS, (int(v) for v in a.tolist())))
-            d["sum_reward"] = float(b.item())
-            per_rank.append(d)
+        got = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(got, rec, group=group)
+        rows = [g.tolist() for g in got]
+    per_rank = []
+    nk = len(STAT_KEYS)
+    for row in rows:
+        d = dict(zip(STAT_KEYS, (int(v) for v in row[:nk])))
+        d["sum_reward"] = struct.unpack("<d", struct.pack("<q", int(row[nk])))[0]
+        for k, v in zip(extra.keys(), row[nk + 1:]):
+            d[k] = int(v)
+        per_rank.append(d)
     total = {k: sum(d[k] for d in per_rank) for k in STAT_KEYS}
     total["sum_reward"] = sum(d["sum_reward"] for d in per_rank)
     return per_rank, total

@@ -6,9 +6,10 @@ envs/collision_avoidence_env.py, ALAN = ALAN/ALAN_true.py).
 """
 from math import pi, sqrt
 
-SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN_DEADLOCK = range(7)
+SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN_DEADLOCK, SCN_CROWD_SEPARATED = range(8)
 SCENARIO_IDS = {"crowd": SCN_CROWD, "circle": SCN_CIRCLE, "doorway": SCN_DOORWAY, "congested": SCN_CONGESTED,
-                "incoming": SCN_INCOMING, "blocks": SCN_BLOCKS, "deadlock": SCN_DEADLOCK}
+                "incoming": SCN_INCOMING, "blocks": SCN_BLOCKS, "deadlock": SCN_DEADLOCK,
+                "crowd_separated": SCN_CROWD_SEPARATED}   # the crowd with starts >= 2 r apart (SURVEY 8d variant)
 SCENARIO_NAMES = {v: k for k, v in SCENARIO_IDS.items()}
 
 DONE_XLESS, DONE_GOAL, DONE_REGOAL = 0, 1, 2
@@ -32,7 +33,7 @@ def circle_envsize(n_agents, radius=0.5):
 def envsize(scenario, n_agents, radius=0.5):
     """The world size each ALAN scenario derives from the agent count."""
     scenario = SCENARIO_NAMES.get(scenario, scenario)
-    if scenario == "crowd":
+    if scenario in ("crowd", "crowd_separated"):
         return crowd_envsize(n_agents, radius)
     if scenario == "circle":
         return circle_envsize(n_agents, radius)
@@ -52,6 +53,8 @@ def obstacles(scenario, n_agents, radius=0.5, seed=0):
     "blocks" scenario (ALAN:364-372; the same layout for every arena of a handle)."""
     scenario = SCENARIO_NAMES.get(scenario, scenario)
     r = radius
+    if scenario == "crowd_separated":
+        scenario = "crowd"
     if scenario == "congested":                                            # ALAN:195-208
         e = envsize(scenario, n_agents, r)
         return [_rect((-e, 0.0), (-e, e), (e, e), (e, 0.0)),

@@ -65,6 +65,7 @@ extern "C" {
 #define CA_SCN_INCOMING 4  /* ALAN:213-267 */
 #define CA_SCN_BLOCKS 5    /* ALAN:333-374 (block obstacles come through ca_set_obstacles)       */
 #define CA_SCN_DEADLOCK 6  /* ALAN:377-457 */
+#define CA_SCN_CROWD_SEPARATED 7 /* the crowd with rejection-sampled starts >= 2 r apart (SURVEY 8d bench variant) */
 
 /* fields for ca_get / ca_set / ca_field_ptr */
 enum ca_field {

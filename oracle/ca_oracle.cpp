@@ -1110,10 +1110,19 @@ int orc_env_init_scenario(void* env, int32_t scenario) {
             rng2(c.seed, g, i, RNG_HEADING, 0, &u0, &u1);
             sincos64(uniform64(0.0, 2.0 * M_PI, u0), &s, &cs); /* env.py:89-90, ALAN:276-277 */
             ar.vel[i] = mk((float)cs, (float)s);
-            if (scenario == ORC_SCN_CROWD) { /* ALAN:270-283 */
+            if (scenario == ORC_SCN_CROWD || scenario == ORC_SCN_CROWD_SEPARATED) { /* ALAN:270-283 */
                 const double E = std::sqrt(2.0 * r * N) * 2.0;
-                rng2(c.seed, g, i, RNG_POS, 0, &u0, &u1);
-                ar.pos[i] = mk((float)uniform64(0.0, E, u0), (float)uniform64(0.0, E, u1));
+                /* SURVEY 8d rejection-sampled variant: redraw (sequence 1, 2, ... <= 63) while the start is
+                   closer than 2 r to the start of an earlier agent */
+                const int tries = scenario == ORC_SCN_CROWD_SEPARATED ? 64 : 1;
+                const float minSq = sqr(c.radius + c.radius);
+                for (int t = 0; t < tries; ++t) {
+                    rng2(c.seed, g, i, RNG_POS, (uint32_t)t, &u0, &u1);
+                    ar.pos[i] = mk((float)uniform64(0.0, E, u0), (float)uniform64(0.0, E, u1));
+                    bool clear = true;
+                    for (int j = 0; j < i && clear; ++j) clear = !(absSq(ar.pos[i] - ar.pos[j]) < minSq);
+                    if (clear) break;
+                }
                 rng2(c.seed, g, i, RNG_GOAL, 0, &u0, &u1);
                 e->goal_x[q] = uniform64(0.0, E, u0);
                 e->goal_y[q] = uniform64(0.0, E, u1);

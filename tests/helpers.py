@@ -6,7 +6,8 @@ from collision_avoidance_amd import scenarios
 from oracle import oracle as o
 
 SCN = {"crowd": o.SCN_CROWD, "circle": o.SCN_CIRCLE, "doorway": o.SCN_DOORWAY, "congested": o.SCN_CONGESTED,
-       "incoming": o.SCN_INCOMING, "blocks": o.SCN_BLOCKS, "deadlock": o.SCN_DEADLOCK}
+       "incoming": o.SCN_INCOMING, "blocks": o.SCN_BLOCKS, "deadlock": o.SCN_DEADLOCK,
+       "crowd_separated": o.SCN_CROWD_SEPARATED}
 
 
 def scenario_params(scenario, n_agents, **over):

@@ -90,6 +90,8 @@ CASES = [
     ("grid_circle", 2, 256, "circle", dict(), 40, 10),
     ("grid_incoming", 2, 226, "incoming", dict(), 60, 20),
     ("grid_smallrange", 2, 400, "crowd", dict(neighbor_dist=1.5, max_neighbors=5), 40, 10),
+    # SURVEY 8d bench variants: rejection-sampled non-overlapping starts
+    ("separated", 12, 64, "crowd_separated", dict(), 150, 50),
 ]
 
 
@@ -299,16 +301,26 @@ def test_dropin_env_api():
     env.close()
 
 
-def test_full_size_properties():
-    """BASELINE config C3 (4096 x 64): size-independent properties instead of an oracle run."""
+FULL = [  # BASELINE.json configs[1], [2], [4] at their full sizes
+    ("C2", 1024, 16, 1.5, 5, 120),
+    ("C3", 4096, 64, 5.0, 10, 100),
+    ("C5", 256, 512, 5.0, 10, 40),
+]
+
+
+@pytest.mark.parametrize("name,A,N,nd,K,steps", FULL, ids=[c[0] for c in FULL])
+def test_full_size_properties(name, A, N, nd, K, steps):
+    """BASELINE configs C2 (1024 x 16), C3 (4096 x 64), C5 (256 x 512) at full size: the first three arenas against
+    the oracle bit for bit (ORCA rollout with statistics, then full steps with actions, rewards and the observation)
+    and size-independent properties over the whole batch."""
     from collision_avoidance_amd import _lib
-    N, A = 64, 4096
-    p = scenarios.bench_params(N, 5.0, 10)
+    p = scenarios.bench_params(N, nd, K)
     env = H.make_gpu(A, N, "crowd", p, seed=0, use_torch=False)
     small = H.make_oracle(3, N, "crowd", p, seed=0)
-    env.rollout(100, stats=True)
-    small.rollout(100, flags=o.F_STATS)
-    for gf, of in ((_lib.FLD_POS_X, o.FLD_POS_X), (_lib.FLD_VEL_Y, o.FLD_VEL_Y)):
+    env.rollout(steps, stats=True)
+    small.rollout(steps, flags=o.F_STATS)
+    for gf, of in ((_lib.FLD_POS_X, o.FLD_POS_X), (_lib.FLD_POS_Y, o.FLD_POS_Y), (_lib.FLD_VEL_X, o.FLD_VEL_X),
+                   (_lib.FLD_VEL_Y, o.FLD_VEL_Y), (_lib.FLD_GOAL_X, o.FLD_GOAL_X), (_lib.FLD_REGOAL_COUNT, o.FLD_REGOAL_COUNT)):
         np.testing.assert_array_equal(env.get(gf)[:3], small.get(of))       # a slice against the oracle
     vx, vy = env.get(_lib.FLD_VEL_X), env.get(_lib.FLD_VEL_Y)
     assert np.isfinite(vx).all() and np.isfinite(vy).all()
@@ -316,18 +328,37 @@ def test_full_size_properties():
     # agents overlap): the oracle shows the same overshoot, bit for bit
     assert np.hypot(vx, vy).max() <= 1.0 + 2e-2
     cnt, idx = env.neighbor_lists()
-    assert cnt.max() <= 10 and cnt.min() >= 0
+    assert cnt.max() <= K and cnt.min() >= 0
     px, py = env.get(_lib.FLD_POS_X), env.get(_lib.FLD_POS_Y)
     a = np.arange(A)[:, None, None]
     d = np.hypot(px[a, idx.clip(0)] - px[:, :, None], py[a, idx.clip(0)] - py[:, :, None])
-    valid = np.arange(10)[None, None, :] < cnt[:, :, None]
+    valid = np.arange(K)[None, None, :] < cnt[:, :, None]
     assert not np.any(valid & (idx == np.arange(N)[None, :, None]))            # never itself
+    assert np.all((idx >= 0) | ~valid) and np.all((idx < N) | ~valid)
     # lists are those of the last doStep (pre-update positions); both agents moved <= maxSpeed*dt since
-    assert np.all(d[valid] < 5.0 + 2 * 1.02 / 60 + 1e-4)
-    act = np.zeros((A, N), np.float32)
-    ob, rew, done, _ = env.step(act)
-    assert ob.shape == (A, N, 64) and np.isfinite(ob).all() and np.abs(ob[..., :2]).max() <= 5.0 + 1e-4
-    assert np.all(rew <= 1.0 + 1e-5)
+    assert np.all(d[valid] < nd + 2 * 1.02 / 60 + 1e-4)
+    # sorted by the distance of the step that built them: after one step of motion still ascending within 4 v dt
+    dd = np.where(valid, d, np.inf)
+    both = valid[:, :, 1:] & valid[:, :, :-1]
+    assert np.all((dd[:, :, 1:] - dd[:, :, :-1])[both] >= -4 * 1.02 / 60 - 1e-4)
+    rng = np.random.RandomState(5)
+    for s in range(3):                                                     # full steps: actions in, obs out
+        act = rng.uniform(-0.5, 0.5, (A, N)).astype(np.float32)
+        ob, rew, done, _ = env.step(act, stats=True)
+        small.step(act[:3], flags=o.F_OBS | o.F_STATS)
+    assert ob.shape == (A, N, 64) and np.isfinite(ob).all() and np.abs(ob[..., :2]).max() <= nd + 1e-4
+    assert np.all(rew <= 1.0 + 2e-2) and not done.any()
+    H._eq(ob[:3], small.get(o.FLD_OBS), name + " obs slice")
+    H._eq(rew[:3], small.get(o.FLD_REWARD), name + " reward slice")
+    H._eq(env.get(_lib.FLD_POS_X)[:3], small.get(o.FLD_POS_X), name + " pos slice after steps")
+    st = env.stats()
+    assert st["agent_steps"] == A * N * (steps + 3) and st["obst_overflow"] == 0
+    gs, es = env.get(_lib.FLD_ARENA_STATS)[:3], small.get(o.FLD_ARENA_STATS)
+    np.testing.assert_array_equal(gs[:, [0, 1, 2, 3, 4, 6, 7]], es[:, [0, 1, 2, 3, 4, 6, 7]])
+    # rays that hit nothing are exactly zero; a hit lies inside the sensor range and carries the owner's velocity
+    hit = (ob[..., 0::4] != 0) | (ob[..., 1::4] != 0)
+    assert np.all(ob[..., 2::4][~hit] == 0) and np.all(ob[..., 3::4][~hit] == 0)
+    assert np.hypot(ob[..., 0::4], ob[..., 1::4]).max() <= nd * (1 + 1e-6)
     env.close()
 
 
