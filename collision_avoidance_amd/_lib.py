@@ -22,7 +22,8 @@ SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN
 EXPORTS = ("ca_create", "ca_destroy", "ca_last_error", "ca_set_stream", "ca_set_obstacles", "ca_init_scenario", "ca_set",
            "ca_get", "ca_field_ptr", "ca_bind_obs", "ca_reset", "ca_step", "ca_step_host", "ca_orca_step", "ca_observe", "ca_rollout",
            "ca_get_stats", "ca_reset_stats", "ca_sync", "ca_debug_math", "ca_profile", "ca_profile_read", "ca_launch_info",
-           "ca_alan_configure", "ca_alan_step", "ca_alan_rollout", "ca_reset_masked", "ca_get_obstacles")
+           "ca_alan_configure", "ca_alan_step", "ca_alan_rollout", "ca_reset_masked", "ca_get_obstacles",
+           "ca_set_obstacles_per_arena", "ca_get_obstacles_arena")
 
 
 class Config(C.Structure):
@@ -76,6 +77,8 @@ def load():
     L.ca_set_obstacles.argtypes = [vp, vp, vp, i32]
     L.ca_init_scenario.argtypes = [vp, i32]
     L.ca_get_obstacles.argtypes = [vp, vp, vp, vp, i32, C.POINTER(i32)]
+    L.ca_set_obstacles_per_arena.argtypes = [vp, vp, vp, vp]
+    L.ca_get_obstacles_arena.argtypes = [vp, i32, vp, vp, vp, i32, C.POINTER(i32)]
     L.ca_set.argtypes = [vp, i32, vp, sz, i32]
     L.ca_get.argtypes = [vp, i32, vp, sz, i32]
     L.ca_field_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz)]

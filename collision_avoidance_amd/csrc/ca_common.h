@@ -30,10 +30,16 @@ struct StepArgs {
     float* reward;
     float *orient_x, *orient_y;  // unit vector pos -> goal of the CURRENT state (frame of the observation)
     int *agent_done, *arrive_step, *regoal_count;
-    int *nb_count, *nb_idx, *obst_count, *obst_idx;
+    // neighbour lists of the last step, packed: counts [A,N] u16 = agent neighbours | obstacle neighbours << 8;
+    // indices [A,K,N] / [A,S,N] as u8, or u16 when an arena has more than 256 agents / obstacle edges
+    unsigned short* counts;
+    void *nb_idx, *obst_idx;
+    int nidx16, oidx16;
     int *step_count, *arena_done, *episode;
     unsigned long long* arena_stats;  // [A][8]
-    const ObstDev* obst;
+    const ObstDev* obst;   // the processed edge table(s)
+    const int* tab_off;    // null: one table of n_obst edges for every arena; else [A + 1] offsets: arena a owns
+                           // edges [tab_off[a], tab_off[a + 1]) and its obstacle-neighbour ids count from tab_off[a]
     const float* actions;  // null: orca_step
     const float* reset_px; // explicit reset positions (reset kernel only)
     const float* reset_py;
@@ -66,6 +72,15 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// packed list entries
+__device__ __forceinline__ int ld_idx(const void* b, size_t k, int w16) {
+    return w16 ? (int)reinterpret_cast<const unsigned short*>(b)[k] : (int)reinterpret_cast<const unsigned char*>(b)[k];
+}
+__device__ __forceinline__ void st_idx(void* b, size_t k, int v, int w16) {
+    if (w16) reinterpret_cast<unsigned short*>(b)[k] = (unsigned short)v;
+    else reinterpret_cast<unsigned char*>(b)[k] = (unsigned char)v;
 }
 
 __device__ __forceinline__ ObstDev load_obst(const ObstDev* __restrict__ t, int i) {

@@ -28,8 +28,13 @@ struct ca_env {
           *pref_y = nullptr, *reward = nullptr, *orient_x = nullptr, *orient_y = nullptr;
     bool orient_valid = false;  // orient_x/y match pos/goal (false after the caller edits them)
     double *goal_x = nullptr, *goal_y = nullptr, *goal2_x = nullptr, *goal2_y = nullptr;  // fp64 targets
-    int *agent_done = nullptr, *arrive_step = nullptr, *regoal_count = nullptr, *nb_count = nullptr,
-        *nb_idx = nullptr, *obst_count = nullptr, *obst_idx = nullptr;
+    int *agent_done = nullptr, *arrive_step = nullptr, *regoal_count = nullptr;
+    // neighbour lists, packed (ca_common.h StepArgs): counts u16 [A,N]; indices u8 or u16 [A,K,N] / [A,S,N]
+    unsigned short* counts = nullptr;
+    void *nb_idx = nullptr, *obst_idx = nullptr;
+    int nidx16 = 0, oidx16 = 0;
+    int* cvt_buf = nullptr;  // staging of the i32 image the ABI shows for the packed fields (ca_get / ca_set)
+    size_t cvt_cap = 0;
     int *step_count = nullptr, *arena_done = nullptr, *episode = nullptr;
     unsigned long long* arena_stats = nullptr;
     float* obs = nullptr;
@@ -46,7 +51,9 @@ struct ca_env {
     double act_c[CA_ALAN_MAX_ACTIONS], act_s[CA_ALAN_MAX_ACTIONS];
     double alan_temp = 0.2, alan_window = 2.0, alan_dt = 1.0 / 60.0;
     ObstDev* d_obst = nullptr;
-    std::vector<ObstDev> h_obst;
+    std::vector<ObstDev> h_obst;     // every table, concatenated
+    std::vector<int> h_tab_off;      // empty: one table for all arenas; else [A + 1] offsets into h_obst
+    int* d_tab_off = nullptr;
     int P = 1, logP = 0, BS = 64, grid = 1, K = 0, S = 1;
     int BSn = 64, grid_n = 1;  // the neighbour kernel's own workgroup size
     bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
@@ -125,9 +132,10 @@ static FieldInfo field_info(ca_env* e, int f) {
         case CA_FLD_REWARD: return {e->reward, an * 4, false};
         case CA_FLD_AGENT_DONE: return {e->agent_done, an * 4, true};
         case CA_FLD_ARRIVE_STEP: return {e->arrive_step, an * 4, true};
-        case CA_FLD_NB_COUNT: return {e->nb_count, an * 4, true};
+        // packed in device memory; the ABI shows them as i32 (ca_get / ca_set convert, ca_field_ptr refuses)
+        case CA_FLD_NB_COUNT: return {e->counts, an * 4, true};
         case CA_FLD_NB_IDX: return {e->nb_idx, an * 4 * (size_t)(e->K > 0 ? e->K : 1), true};
-        case CA_FLD_OBST_COUNT: return {e->obst_count, an * 4, true};
+        case CA_FLD_OBST_COUNT: return {e->counts, an * 4, true};
         case CA_FLD_OBST_IDX: return {e->obst_idx, an * 4 * (size_t)e->S, true};
         case CA_FLD_OBS: return {e->obs, an * CA_OBS_DIM * 4, false};
         case CA_FLD_STEP_COUNT: return {e->step_count, A * 4, true};
@@ -171,12 +179,13 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.goal2_x = e->goal2_x; a.goal2_y = e->goal2_y; a.reward = e->reward;
     a.orient_x = e->orient_x; a.orient_y = e->orient_y;
     a.agent_done = e->agent_done; a.arrive_step = e->arrive_step; a.regoal_count = e->regoal_count;
-    a.nb_count = e->nb_count; a.nb_idx = e->nb_idx; a.obst_count = e->obst_count; a.obst_idx = e->obst_idx;
+    a.counts = e->counts; a.nb_idx = e->nb_idx; a.obst_idx = e->obst_idx; a.nidx16 = e->nidx16; a.oidx16 = e->oidx16;
+    a.tab_off = e->d_tab_off;
     a.step_count = e->step_count; a.arena_done = e->arena_done; a.episode = e->episode;
     a.arena_stats = e->arena_stats; a.obst = e->d_obst; a.actions = actions;
     a.reset_px = nullptr; a.reset_py = nullptr; a.reset_mask = nullptr; a.dbg = e->dbg;
     a.reward_scale = c.reward_scale; a.seed = c.seed; a.arena_offset = c.arena_offset;
-    a.n_obst = (int)e->h_obst.size(); a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
+    a.n_obst = e->h_tab_off.empty() ? (int)e->h_obst.size() : 0; a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
     a.K = e->K; a.S = e->S; a.flags = flags; a.a0 = 0; a.a1 = c.n_arenas;
     a.time_step = c.time_step; a.neighbor_dist = c.neighbor_dist; a.time_horizon = c.time_horizon;
     a.time_horizon_obst = c.time_horizon_obst; a.radius = c.radius; a.max_speed = c.max_speed;
@@ -253,8 +262,9 @@ static hipError_t launch_obs(ca_env* e) {
     }
     ObsArgs o;
     o.pos_x = e->pos_x; o.pos_y = e->pos_y; o.vel_x = e->vel_x; o.vel_y = e->vel_y;
-    o.orient_x = e->orient_x; o.orient_y = e->orient_y; o.nb_count = e->nb_count; o.nb_idx = e->nb_idx;
-    o.obst_count = e->obst_count; o.obst_idx = e->obst_idx; o.obst = e->d_obst; o.obs = e->obs;
+    o.orient_x = e->orient_x; o.orient_y = e->orient_y; o.counts = e->counts; o.nb_idx = e->nb_idx;
+    o.obst_idx = e->obst_idx; o.nidx16 = e->nidx16; o.oidx16 = e->oidx16; o.obst = e->d_obst; o.tab_off = e->d_tab_off;
+    o.obs = e->obs;
     o.A = e->cfg.n_arenas; o.N = e->cfg.n_agents; o.S = e->S;
     o.K = e->K > 0 ? e->K : 1;  // nb_idx is allocated with one column when K == 0; counts are all zero
     const int obs_bs = obs_block_threads(o.N), apb = obs_bs / 16;
@@ -437,10 +447,13 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     for (auto p : f32s) if (r == hipSuccess) r = dalloc(e, p, an);
     double** f64s[] = {&e->goal_x, &e->goal_y, &e->goal2_x, &e->goal2_y};
     for (auto p : f64s) if (r == hipSuccess) r = dalloc(e, p, an);
-    int** i32s[] = {&e->agent_done, &e->arrive_step, &e->regoal_count, &e->nb_count, &e->obst_count};
+    int** i32s[] = {&e->agent_done, &e->arrive_step, &e->regoal_count};
     for (auto p : i32s) if (r == hipSuccess) r = dalloc(e, p, an);
-    if (r == hipSuccess) r = dalloc(e, &e->nb_idx, an * (size_t)(e->K > 0 ? e->K : 1));
-    if (r == hipSuccess) r = dalloc(e, &e->obst_idx, an * (size_t)e->S);
+    e->nidx16 = cfg->n_agents > 256 ? 1 : 0;  // u8 indices address 256 agents
+    if (r == hipSuccess) r = dalloc(e, &e->counts, an);
+    if (r == hipSuccess) r = dalloc(e, reinterpret_cast<unsigned char**>(&e->nb_idx),
+                                    an * (size_t)(e->K > 0 ? e->K : 1) * (e->nidx16 ? 2 : 1));
+    if (r == hipSuccess) r = dalloc(e, reinterpret_cast<unsigned short**>(&e->obst_idx), an * (size_t)e->S);  // u8 or u16
     if (r == hipSuccess) r = dalloc(e, &e->step_count, A);
     if (r == hipSuccess) r = dalloc(e, &e->arena_done, A);
     if (r == hipSuccess) r = dalloc(e, &e->episode, A);
@@ -484,7 +497,7 @@ int ca_destroy(ca_env* e) {
     void* bufs[] = {e->pos_x, e->pos_y, e->vel_x, e->vel_y, e->pref_x, e->pref_y, e->goal_x, e->goal_y,
                     e->goal2_x, e->goal2_y, e->reward, e->tmp_x, e->tmp_y, e->orient_x, e->orient_y,
                     e->agent_done, e->arrive_step,
-                    e->regoal_count, e->nb_count, e->nb_idx, e->obst_count, e->obst_idx, e->step_count,
+                    e->regoal_count, e->counts, e->nb_idx, e->obst_idx, e->cvt_buf, e->d_tab_off, e->step_count,
                     e->arena_done, e->episode, e->arena_stats, e->d_obst, e->dbg, e->dbg_obs,
                     e->alan_w, e->alan_t, e->alan_dirs, e->alan_u, e->alan_action, e->mask_buf};
     for (void* b : bufs) if (b) hipFree(b);
@@ -506,9 +519,8 @@ int ca_set_stream(ca_env* e, void* stream) {
     return CA_OK;
 }
 
-int ca_set_obstacles(ca_env* e, const float* verts_xy, const int32_t* poly_sizes, int32_t n_poly) {
-    if (!e || n_poly < 0 || (n_poly > 0 && (!verts_xy || !poly_sizes))) return fail(e, CA_EINVAL, "ca_set_obstacles: bad argument");
-    std::vector<ObstDev> tab;
+// addObstacle for every polygon + processObstacles (env.py:118-123, 143-149): one processed edge table
+static int build_table(ca_env* e, const float* verts_xy, const int32_t* poly_sizes, int n_poly, std::vector<ObstDev>& tab) {
     size_t off = 0;
     for (int pi = 0; pi < n_poly; ++pi) {
         const int n = poly_sizes[pi];
@@ -536,26 +548,100 @@ int ca_set_obstacles(ca_env* e, const float* verts_xy, const int32_t* poly_sizes
         o.qx = nx.px; o.qy = nx.py; o.qux = nx.ux; o.quy = nx.uy; o.qconvex = nx.convex;
         o.pux = pv.ux; o.puy = pv.uy;
     }
+    return CA_OK;
+}
+
+__global__ void clear_obst_counts_kernel(unsigned short* counts, unsigned n) {
+    const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) counts[q] &= 0x00FFu;
+}
+
+// installs the table(s): `all` = every table concatenated, `offs` empty (one table for all arenas) or [A + 1]
+static int install_tables(ca_env* e, std::vector<ObstDev>& all, std::vector<int>& offs, size_t largest) {
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (e->d_obst) HIPCHK(e, hipFree(e->d_obst));
     e->d_obst = nullptr;
-    HIPCHK(e, hipMalloc((void**)&e->d_obst, (tab.size() + 1) * sizeof(ObstDev)));
-    if (!tab.empty()) HIPCHK(e, upload(e, e->d_obst, tab.data(), tab.size() * sizeof(ObstDev)));
-    e->h_obst.swap(tab);
+    if (e->d_tab_off) HIPCHK(e, hipFree(e->d_tab_off));
+    e->d_tab_off = nullptr;
+    HIPCHK(e, hipMalloc((void**)&e->d_obst, (all.size() + 1) * sizeof(ObstDev)));
+    if (!all.empty()) HIPCHK(e, upload(e, e->d_obst, all.data(), all.size() * sizeof(ObstDev)));
+    if (!offs.empty()) {
+        HIPCHK(e, hipMalloc((void**)&e->d_tab_off, offs.size() * sizeof(int)));
+        HIPCHK(e, upload(e, e->d_tab_off, offs.data(), offs.size() * sizeof(int)));
+    }
+    const int w16 = largest > 256 ? 1 : 0;  // u8 ids address 256 edges
+    if (w16 != e->oidx16) {  // the stored obstacle-neighbour ids change width: the (stale anyway) lists are emptied
+        const unsigned an = (unsigned)AN(e);
+        hipLaunchKernelGGL(clear_obst_counts_kernel, dim3((an + 255) / 256), dim3(256), 0, e->stream, e->counts, an);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        e->oidx16 = w16;
+    }
+    e->h_obst.swap(all);
+    e->h_tab_off.swap(offs);
+    return CA_OK;
+}
+
+int ca_set_obstacles(ca_env* e, const float* verts_xy, const int32_t* poly_sizes, int32_t n_poly) {
+    if (!e || n_poly < 0 || (n_poly > 0 && (!verts_xy || !poly_sizes))) return fail(e, CA_EINVAL, "ca_set_obstacles: bad argument");
+    std::vector<ObstDev> tab;
+    const int rc = build_table(e, verts_xy, poly_sizes, n_poly, tab);
+    if (rc) return rc;
+    if (tab.size() > 65536) return fail(e, CA_ERANGE, "ca_set_obstacles: %zu edges (at most 65536)", tab.size());
+    std::vector<int> none;
+    const size_t n = tab.size();
+    return install_tables(e, tab, none, n);
+}
+
+int ca_set_obstacles_per_arena(ca_env* e, const float* verts_xy, const int32_t* poly_sizes, const int32_t* n_poly) {
+    if (!e || !n_poly) return fail(e, CA_EINVAL, "ca_set_obstacles_per_arena: null argument");
+    const int A = e->cfg.n_arenas;
+    std::vector<ObstDev> all;
+    std::vector<int> offs(1, 0);
+    size_t voff = 0, poff = 0, largest = 0;
+    for (int a = 0; a < A; ++a) {
+        if (n_poly[a] < 0 || (n_poly[a] > 0 && (!verts_xy || !poly_sizes)))
+            return fail(e, CA_EINVAL, "ca_set_obstacles_per_arena: bad argument for arena %d", a);
+        std::vector<ObstDev> tab;
+        const int rc = build_table(e, verts_xy ? verts_xy + 2 * voff : nullptr, poly_sizes ? poly_sizes + poff : nullptr,
+                                   n_poly[a], tab);
+        if (rc) return rc;
+        for (int k = 0; k < n_poly[a]; ++k) voff += (size_t)poly_sizes[poff + k];
+        poff += (size_t)n_poly[a];
+        if (tab.size() > 65536) return fail(e, CA_ERANGE, "ca_set_obstacles_per_arena: arena %d has %zu edges (at most 65536)", a, tab.size());
+        largest = std::max(largest, tab.size());
+        all.insert(all.end(), tab.begin(), tab.end());  // next / prev stay local to the arena's table
+        if (all.size() > (size_t)0x7FFFFFFF) return fail(e, CA_ERANGE, "ca_set_obstacles_per_arena: too many edges");
+        offs.push_back((int)all.size());
+    }
+    return install_tables(e, all, offs, largest);
+}
+
+static int get_table(ca_env* e, int arena, float* verts_xy, int32_t* next, int32_t* convex, int32_t cap, int32_t* n_out) {
+    const bool per = !e->h_tab_off.empty();
+    const int t0 = per ? e->h_tab_off[arena] : 0;
+    const int n = per ? e->h_tab_off[arena + 1] - t0 : (int)e->h_obst.size();
+    *n_out = n;
+    for (int i = 0; i < n && i < cap; ++i) {
+        const ObstDev& o = e->h_obst[t0 + i];
+        if (verts_xy) { verts_xy[2 * i] = o.px; verts_xy[2 * i + 1] = o.py; }
+        if (next) next[i] = o.next;
+        if (convex) convex[i] = o.convex;
+    }
     return CA_OK;
 }
 
 int ca_get_obstacles(ca_env* e, float* verts_xy, int32_t* next, int32_t* convex, int32_t cap, int32_t* n_out) {
     if (!e || !n_out) return fail(e, CA_EINVAL, "ca_get_obstacles: null argument");
-    const int n = (int)e->h_obst.size();
-    *n_out = n;
-    for (int i = 0; i < n && i < cap; ++i) {
-        if (verts_xy) { verts_xy[2 * i] = e->h_obst[i].px; verts_xy[2 * i + 1] = e->h_obst[i].py; }
-        if (next) next[i] = e->h_obst[i].next;
-        if (convex) convex[i] = e->h_obst[i].convex;
-    }
-    return CA_OK;
+    return get_table(e, 0, verts_xy, next, convex, cap, n_out);
+}
+
+int ca_get_obstacles_arena(ca_env* e, int32_t arena, float* verts_xy, int32_t* next, int32_t* convex, int32_t cap,
+                           int32_t* n_out) {
+    if (!e || !n_out) return fail(e, CA_EINVAL, "ca_get_obstacles_arena: null argument");
+    if (arena < 0 || arena >= e->cfg.n_arenas) return fail(e, CA_ERANGE, "ca_get_obstacles_arena: arena %d of %d", arena, e->cfg.n_arenas);
+    return get_table(e, arena, verts_xy, next, convex, cap, n_out);
 }
 
 int ca_init_scenario(ca_env* e, int32_t scenario) {
@@ -664,14 +750,43 @@ int ca_init_scenario(ca_env* e, int32_t scenario) {
     HIPCHK(e, hipMemsetAsync(e->agent_done, 0, an * 4, st));
     HIPCHK(e, hipMemsetAsync(e->arrive_step, 0xff, an * 4, st));
     HIPCHK(e, hipMemsetAsync(e->regoal_count, 0, an * 4, st));
-    HIPCHK(e, hipMemsetAsync(e->nb_count, 0, an * 4, st));
-    HIPCHK(e, hipMemsetAsync(e->obst_count, 0, an * 4, st));
+    HIPCHK(e, hipMemsetAsync(e->counts, 0, an * 2, st));
     HIPCHK(e, hipMemsetAsync(e->step_count, 0, (size_t)A * 4, st));
     HIPCHK(e, hipMemsetAsync(e->arena_done, 0, (size_t)A * 4, st));
     HIPCHK(e, hipMemsetAsync(e->episode, 0, (size_t)A * 4, st));
     HIPCHK(e, hipMemsetAsync(e->obs, 0, an * CA_OBS_DIM * 4, st));
     HIPCHK(e, hipStreamSynchronize(st));  // the host vectors above go out of scope
     e->orient_valid = false;
+    return CA_OK;
+}
+
+// The packed neighbour-list fields keep their ABI image (i32 arrays, include/ca_env.h) through two small kernels.
+__global__ void unpack_list_kernel(const void* src, int kind, int w16, int* dst, size_t n) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    if (kind == 0) dst[q] = (int)(reinterpret_cast<const unsigned short*>(src)[q] & 0xFFu);       // agent-neighbour count
+    else if (kind == 1) dst[q] = (int)(reinterpret_cast<const unsigned short*>(src)[q] >> 8);      // obstacle-neighbour count
+    else dst[q] = ld_idx(src, q, w16);
+}
+__global__ void pack_list_kernel(const int* src, int kind, int w16, void* dst, size_t n) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    unsigned short* c = reinterpret_cast<unsigned short*>(dst);
+    if (kind == 0) c[q] = (unsigned short)((c[q] & 0xFF00u) | ((unsigned)src[q] & 0xFFu));
+    else if (kind == 1) c[q] = (unsigned short)((c[q] & 0x00FFu) | (((unsigned)src[q] & 0xFFu) << 8));
+    else st_idx(dst, q, src[q], w16);
+}
+static bool packed_field(int f) {
+    return f == CA_FLD_NB_COUNT || f == CA_FLD_OBST_COUNT || f == CA_FLD_NB_IDX || f == CA_FLD_OBST_IDX;
+}
+static int packed_kind(int f) { return f == CA_FLD_NB_COUNT ? 0 : (f == CA_FLD_OBST_COUNT ? 1 : 2); }
+static int cvt_reserve(ca_env* e, size_t elems) {
+    if (e->cvt_cap >= elems) return CA_OK;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->cvt_buf) HIPCHK(e, hipFree(e->cvt_buf));
+    e->cvt_buf = nullptr; e->cvt_cap = 0;
+    HIPCHK(e, hipMalloc((void**)&e->cvt_buf, elems * sizeof(int)));
+    e->cvt_cap = elems;
     return CA_OK;
 }
 
@@ -682,6 +797,17 @@ int ca_set(ca_env* e, int32_t field, const void* src, size_t bytes, int32_t src_
     if (!fi.writable) return fail(e, CA_EINVAL, "ca_set: field %d is read-only", field);
     if (bytes != fi.bytes) return fail(e, CA_ESIZE, "ca_set: field %d holds %zu bytes, got %zu", field, fi.bytes, bytes);
     HIPCHK(e, hipSetDevice(e->device));
+    if (packed_field(field)) {
+        const size_t n = bytes / 4;
+        const int rc = cvt_reserve(e, n);
+        if (rc) return rc;
+        HIPCHK(e, hipMemcpyAsync(e->cvt_buf, src, bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(pack_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->cvt_buf,
+                           packed_kind(field), field == CA_FLD_NB_IDX ? e->nidx16 : e->oidx16, fi.ptr, n);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipStreamSynchronize(e->stream));  // the staging buffer is free again, the caller's host array too
+        return CA_OK;
+    }
     HIPCHK(e, hipMemcpyAsync(fi.ptr, src, bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
     if (!src_is_device) HIPCHK(e, hipStreamSynchronize(e->stream));
     if (field == CA_FLD_POS_X || field == CA_FLD_POS_Y || field == CA_FLD_GOAL_X || field == CA_FLD_GOAL_Y)
@@ -695,6 +821,17 @@ int ca_get(ca_env* e, int32_t field, void* dst, size_t bytes, int32_t dst_is_dev
     if (!fi.ptr) return fail(e, CA_EINVAL, "ca_get: unknown field %d", field);
     if (bytes != fi.bytes) return fail(e, CA_ESIZE, "ca_get: field %d holds %zu bytes, got %zu", field, fi.bytes, bytes);
     HIPCHK(e, hipSetDevice(e->device));
+    if (packed_field(field)) {
+        const size_t n = bytes / 4;
+        const int rc = cvt_reserve(e, n);
+        if (rc) return rc;
+        hipLaunchKernelGGL(unpack_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, fi.ptr,
+                           packed_kind(field), field == CA_FLD_NB_IDX ? e->nidx16 : e->oidx16, e->cvt_buf, n);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipMemcpyAsync(dst, e->cvt_buf, bytes, dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        return CA_OK;
+    }
     HIPCHK(e, hipMemcpyAsync(dst, fi.ptr, bytes, dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
     if (!dst_is_device) HIPCHK(e, hipStreamSynchronize(e->stream));
     return CA_OK;
@@ -704,6 +841,8 @@ int ca_field_ptr(ca_env* e, int32_t field, void** dev_ptr, size_t* bytes) {
     if (!e || !dev_ptr) return fail(e, CA_EINVAL, "ca_field_ptr: null argument");
     const FieldInfo fi = field_info(e, field);
     if (!fi.ptr) return fail(e, CA_EINVAL, "ca_field_ptr: unknown field %d", field);
+    if (packed_field(field))
+        return fail(e, CA_EINVAL, "ca_field_ptr: field %d is stored packed (u8/u16); read it through ca_get", field);
     *dev_ptr = fi.ptr;
     if (bytes) *bytes = fi.bytes;
     return CA_OK;

@@ -86,17 +86,25 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
     int oin = 0;
     {
         const float rangeSq = sqr(p.time_horizon_obst * p.max_speed + p.radius);
-        for (int e = 0; e < p.n_obst; ++e) {
-            const ObstDev o1 = p.obst[e];
+        auto visit = [&](const ObstDev& o1, int e, bool mine) __attribute__((always_inline)) {
             const V2 a1 = mk(o1.px, o1.py), a2 = mk(o1.qx, o1.qy);
             const float alol = leftOf(a1, a2, pos);
             const float dsl = sqr(alol) / absSq(a2 - a1);
-            if (active && dsl < rangeSq && alol < 0.0f) {
+            if (mine && dsl < rangeSq && alol < 0.0f) {
                 const float dsq = distSqPointSegment(a1, a2, pos);
                 if (dsq < rangeSq) {
                     ++oin;
                     sorted_insert<SMAX>(okey, make_key(dsq, e));
                 }
+            }
+        };
+        if (p.tab_off == nullptr) {  // one table for every arena: uniform loop, scalar loads of the edge records
+            for (int e = 0; e < p.n_obst; ++e) visit(p.obst[e], e, active);
+        } else {                     // a table per arena (several arenas may share this wave): ids are local to it
+            const int t0 = active ? p.tab_off[a] : 0, ne = active ? p.tab_off[a + 1] - t0 : 0;
+            for (int e = 0; __ballot(e < ne) != 0ull; ++e) {
+                const bool mine = e < ne;
+                visit(load_obst(p.obst, mine ? t0 + e : 0), e, mine);
             }
         }
     }
@@ -245,14 +253,13 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
     CA_STAMP(14);
     if (active) {
         if (oin > S) atomicAdd(reinterpret_cast<int*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_OVERFLOW]), 1);
-        p.nb_count[q] = ncnt;
-        p.obst_count[q] = ocnt;
+        p.counts[q] = (unsigned short)(ncnt | (ocnt << 8));
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-            if (k >= kofs) p.nb_idx[((size_t)a * K + (k - kofs)) * N + i] = key_index(nkey[k]);
+            if (k >= kofs) st_idx(p.nb_idx, ((size_t)a * K + (k - kofs)) * N + i, key_index(nkey[k]), p.nidx16);
 #pragma unroll
         for (int k = 0; k < SMAX; ++k)
-            if (k >= sofs) p.obst_idx[((size_t)a * S + (k - sofs)) * N + i] = key_index(okey[k]);
+            if (k >= sofs) st_idx(p.obst_idx, ((size_t)a * S + (k - sofs)) * N + i, key_index(okey[k]), p.oidx16);
     }
     CA_STAMP(15);
 }

@@ -23,8 +23,11 @@ namespace ca {
 // ============================================================================================
 struct ObsArgs {
     const float *pos_x, *pos_y, *vel_x, *vel_y, *orient_x, *orient_y;
-    const int *nb_count, *nb_idx, *obst_count, *obst_idx;
+    const unsigned short* counts;       // packed like StepArgs
+    const void *nb_idx, *obst_idx;
+    int nidx16, oidx16;
     const ObstDev* obst;
+    const int* tab_off;                 // null or [A + 1]: per-arena edge tables (see StepArgs)
     float* obs;
     int A, N, K, S, bpa;  // bpa = workgroups per arena = ceil(N / 16)
     int a0;               // first arena of this launch
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     const int i = (blockIdx.x - ab * p.bpa) * OBS_APB + g;
     const bool active = i < N;
     const size_t q = (size_t)a * N + (active ? i : 0);
+    const ObstDev* tab = p.obst + (p.tab_off ? p.tab_off[a] : 0);  // this arena's edge table
 
     float* s_px = reinterpret_cast<float*>(smem4);
     float* s_py = s_px + N;
@@ -135,10 +139,11 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     int nn = 0, ns = 0;
     float c = 1.0f, s = 0.0f;
     if (active) {
-        nn = p.nb_count[q]; ns = p.obst_count[q];
+        const int cnts = p.counts[q];
+        nn = cnts & 0xFF; ns = cnts >> 8;
         c = p.orient_x[q]; s = -p.orient_y[q];  // utils.py:48-51: cos/sin of -atan2(orientation)
-        if (r < nn) s_nb[g * 16 + r] = p.nb_idx[((size_t)a * K + r) * N + i];
-        if (r < ns) s_ob[g * 8 + r] = p.obst_idx[((size_t)a * S + r) * N + i];
+        if (r < nn) s_nb[g * 16 + r] = ld_idx(p.nb_idx, ((size_t)a * K + r) * N + i, p.nidx16);
+        if (r < ns) s_ob[g * 8 + r] = ld_idx(p.obst_idx, ((size_t)a * S + r) * N + i, p.oidx16);
     }
     s_key[g * 16 + r] = ~0ull;
     if (r == 0) { s_cnt[g] = 0; s_cnt2[g] = 0; }
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         const float dx = s_rays[2 * r], dy = s_rays[2 * r + 1];
         int cnt2 = 0;
         for (int sidx = 0; sidx < ns; ++sidx) {
-            const ObstDev o1 = load_obst(p.obst, s_ob[g * 8 + sidx]);
+            const ObstDev o1 = load_obst(tab, s_ob[g * 8 + sidx]);
             const float x1 = o1.px - mx, y1 = o1.py - my, x2 = o1.qx - mx, y2 = o1.qy - my;
             const float ax = c * x1 - s * y1, ay = s * x1 + c * y1;
             const float bx = c * x2 - s * y2, by = s * x2 + c * y2;
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             x2 = oc.z + rx; y2 = oc.w + ry;
             if (want_vel) { vx = s_vx[nb]; vy = s_vy[nb]; }  // env.py:252
         } else {
-            const ObstDev o1 = load_obst(p.obst, s_ob[g * 8 + (m - 8 * nn)]);
+            const ObstDev o1 = load_obst(tab, s_ob[g * 8 + (m - 8 * nn)]);
             x1 = o1.px - mx; y1 = o1.py - my;
             x2 = o1.qx - mx; y2 = o1.qy - my;
         }

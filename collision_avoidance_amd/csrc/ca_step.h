@@ -59,21 +59,24 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     CA_STAMP(0);
     // ---- load own state (coalesced SoA) ----
     V2 pos = mk(0.0f, 0.0f), vel = mk(0.0f, 0.0f), pref = mk(0.0f, 0.0f);
-    double gx = 0.0, gy = 0.0;
     int done = 1;
-    double pf_x = 1.0, pf_y = 0.0, rl_x = 1.0, rl_y = 0.0;
+    // goal direction and action-rotated direction of env.py:375-381, rounded to fp32 as the reward uses them (env.py:394-399
+    // on the simulator's floats); the fp64 targets are read again where the done test needs them, instead of living
+    // in four registers across the solve
+    V2 pf32 = mk(1.0f, 0.0f), rl32 = mk(1.0f, 0.0f);
     if (active) {
         pos = mk(p.pos_x[q], p.pos_y[q]);
         vel = mk(p.vel_x[q], p.vel_y[q]);
-        gx = p.goal_x[q]; gy = p.goal_y[q];
         done = p.agent_done[q];
         if (p.actions) {  // env.py:371-383
-            pref_dir64(pos.x, pos.y, gx, gy, &pf_x, &pf_y);
-            double sn, cs;
+            double pf_x, pf_y, sn, cs;
+            pref_dir64(pos.x, pos.y, p.goal_x[q], p.goal_y[q], &pf_x, &pf_y);
             sincos64((double)p.actions[q], &sn, &cs);
-            rl_x = pf_x * cs - pf_y * sn;
-            rl_y = pf_x * sn + pf_y * cs;
-            pref = mk((float)rl_x, (float)rl_y);
+            const double rl_x = pf_x * cs - pf_y * sn;
+            const double rl_y = pf_x * sn + pf_y * cs;
+            pf32 = mk((float)pf_x, (float)pf_y);
+            rl32 = mk((float)rl_x, (float)rl_y);
+            pref = rl32;
         } else {
             pref = mk(p.pref_x[q], p.pref_y[q]);
         }
@@ -83,8 +86,9 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
 
     CA_STAMP(1);
     // ---- neighbour lists of this step (App. A.2), produced by nbr_kernel ----
-    const int ocnt = active ? p.obst_count[q] : 0;
-    const int ncnt = active ? p.nb_count[q] : 0;
+    const int cnts = active ? (int)p.counts[q] : 0;
+    const int ocnt = cnts >> 8, ncnt = cnts & 0xFF;
+    const ObstDev* tab = p.obst + ((p.tab_off != nullptr && active) ? p.tab_off[a] : 0);  // this arena's edge table
     CA_STAMP(2);
     CA_STAMP(3);
     const float R = p.radius;
@@ -96,11 +100,11 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
         int no = 0;  // obstacle lines produced so far (slots [0, no))
         {
             const float invTO = 1.0f / p.time_horizon_obst;
-            int e_next = (ocnt > 0) ? p.obst_idx[((size_t)a * S + 0) * N + i] : 0;
+            int e_next = (ocnt > 0) ? ld_idx(p.obst_idx, ((size_t)a * S + 0) * N + i, p.oidx16) : 0;
             for (int s = 0; s < S; ++s) {
                 if (s < ocnt) {
                     const int e = e_next;
-                    if (s + 1 < ocnt) e_next = p.obst_idx[((size_t)a * S + (s + 1)) * N + i];
+                    if (s + 1 < ocnt) e_next = ld_idx(p.obst_idx, ((size_t)a * S + (s + 1)) * N + i, p.oidx16);
                     auto covered = [&](V2 c1, V2 c2) __attribute__((always_inline)) {
                         bool c = false;
                         static_for<ST>([&](auto jc) __attribute__((always_inline)) {
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
                         return c;
                     };
                     Line line;
-                    if (obst_orca_line(p.obst, e, pos, vel, R, invTO, covered, line)) {
+                    if (obst_orca_line(tab, e, pos, vel, R, invTO, covered, line)) {
                         const float4 pl = pack_line(line);
                         static_for<ST>([&](auto jc) __attribute__((always_inline)) {
                             constexpr int j = decltype(jc)::value;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
             int jn[KMAX];  // all neighbour indices in flight at once
             static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
-                jn[k] = (k < ncnt) ? p.nb_idx[((size_t)a * K + k) * N + i] : 0;
+                jn[k] = (k < ncnt) ? ld_idx(p.nb_idx, ((size_t)a * K + k) * N + i, p.nidx16) : 0;
             });
             static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
@@ -184,11 +188,11 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
         int nl = 0;
     {
         const float invTO = 1.0f / p.time_horizon_obst;
-        int e_next = (ocnt > 0) ? p.obst_idx[((size_t)a * S + 0) * N + i] : 0;
+        int e_next = (ocnt > 0) ? ld_idx(p.obst_idx, ((size_t)a * S + 0) * N + i, p.oidx16) : 0;
         for (int s = 0; s < S; ++s) {
             if (s < ocnt) {
                 const int e = e_next;
-                if (s + 1 < ocnt) e_next = p.obst_idx[((size_t)a * S + (s + 1)) * N + i];
+                if (s + 1 < ocnt) e_next = ld_idx(p.obst_idx, ((size_t)a * S + (s + 1)) * N + i, p.oidx16);
                 Line line;
                 auto covered = [&](V2 c1, V2 c2) {
                     for (int j = 0; j < nl; ++j) {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
                     }
                     return false;
                 };
-                if (obst_orca_line(p.obst, e, pos, vel, R, invTO, covered, line)) {
+                if (obst_orca_line(tab, e, pos, vel, R, invTO, covered, line)) {
                     ls.put(nl, line);
                     ++nl;
                 }
@@ -210,11 +214,11 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     {
         const float invT = 1.0f / p.time_horizon;
         const float invDt = 1.0f / p.time_step;
-        int j_next = (ncnt > 0) ? p.nb_idx[((size_t)a * K + 0) * N + i] : 0;
+        int j_next = (ncnt > 0) ? ld_idx(p.nb_idx, ((size_t)a * K + 0) * N + i, p.nidx16) : 0;
         for (int k = 0; k < K; ++k) {
             if (k < ncnt) {
                 const int j = lbase + j_next;
-                if (k + 1 < ncnt) j_next = p.nb_idx[((size_t)a * K + (k + 1)) * N + i];
+                if (k + 1 < ncnt) j_next = ld_idx(p.nb_idx, ((size_t)a * K + (k + 1)) * N + i, p.nidx16);
                 const Line line = agent_orca_line(pos, vel, mk(s_px[j], s_py[j]), mk(s_vx[j], s_vy[j]), R, invT, invDt);
                 ls.put(nl, line);
                 ++nl;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
             int jn[KMAX];  // all list entries in flight at once
             static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
-                jn[k] = (k < ncnt) ? p.nb_idx[((size_t)a * K + k) * N + i] : 0;
+                jn[k] = (k < ncnt) ? ld_idx(p.nb_idx, ((size_t)a * K + k) * N + i, p.nidx16) : 0;
             });
             static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
@@ -278,9 +282,17 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
         }
         if (active) {
             bool wall = false;
-            for (int e = 0; e < p.n_obst; ++e) {
-                const ObstDev o1 = p.obst[e];
-                if (distSqPointSegment(mk(o1.px, o1.py), mk(o1.qx, o1.qy), pos) < sqr(R)) wall = true;
+            if (p.tab_off == nullptr) {
+                for (int e = 0; e < p.n_obst; ++e) {
+                    const ObstDev o1 = p.obst[e];
+                    if (distSqPointSegment(mk(o1.px, o1.py), mk(o1.qx, o1.qy), pos) < sqr(R)) wall = true;
+                }
+            } else {
+                const int ne = p.tab_off[a + 1] - p.tab_off[a];
+                for (int e = 0; e < ne; ++e) {
+                    const ObstDev o1 = load_obst(tab, e);
+                    if (distSqPointSegment(mk(o1.px, o1.py), mk(o1.qx, o1.qy), pos) < sqr(R)) wall = true;
+                }
             }
             if (pairs) atomicAdd(&red[1], pairs);
             if (wall) atomicAdd(&red[2], 1);
@@ -290,11 +302,13 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     CA_STAMP(8);
     // ---- reward (env.py:389-400) or preferred velocity towards the goal (env.py:449) ----
     float rew = 0.0f;
+    double gx = 0.0, gy = 0.0;
     if (active) {
+        gx = p.goal_x[q]; gy = p.goal_y[q];
         if (p.actions) {
             const float scale = (float)p.reward_scale;
-            const float r_goal = vel.x * (float)pf_x + vel.y * (float)pf_y;
-            const float r_polite = vel.x * (float)rl_x + vel.y * (float)rl_y;
+            const float r_goal = vel.x * pf32.x + vel.y * pf32.y;
+            const float r_polite = vel.x * rl32.x + vel.y * rl32.y;
             rew = scale * r_goal + (1.0f - scale) * r_polite;
             p.reward[q] = rew;
         } else {

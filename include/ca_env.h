@@ -76,10 +76,14 @@ enum ca_field {
     CA_FLD_REWARD,       /* f32 [A,N]                                             */
     CA_FLD_AGENT_DONE,   /* i32 [A,N]                                             */
     CA_FLD_ARRIVE_STEP,  /* i32 [A,N]                                             */
-    CA_FLD_NB_COUNT,     /* i32 [A,N]   ORCA agent-neighbour count (read-only)    */
+    /* the neighbour lists left by the last doStep (sim.getAgentNumAgentNeighbors / getAgentAgentNeighbor /
+       getAgentNumObstacleNeighbors / getAgentObstacleNeighbor, env.py:246-249, 283-285, 305-306).  i32 at this
+       boundary; the device keeps them packed (u16 counts, u8 / u16 ids), so ca_get / ca_set convert and
+       ca_field_ptr refuses them */
+    CA_FLD_NB_COUNT,     /* i32 [A,N]   ORCA agent-neighbour count                */
     CA_FLD_NB_IDX,       /* i32 [A,K,N] ORCA agent neighbours, nearest first      */
     CA_FLD_OBST_COUNT,   /* i32 [A,N]                                             */
-    CA_FLD_OBST_IDX,     /* i32 [A,S,N] ORCA obstacle-edge neighbours             */
+    CA_FLD_OBST_IDX,     /* i32 [A,S,N] ORCA obstacle-edge neighbours: edge ids of the arena's processed table */
     CA_FLD_OBS,          /* f32 [A,N,64]                                          */
     CA_FLD_STEP_COUNT,   /* i32 [A]                                               */
     CA_FLD_ARENA_DONE,   /* i32 [A]                                               */
@@ -144,7 +148,7 @@ const char* ca_last_error(const ca_env* env);
 int ca_set_stream(ca_env* env, void* stream);
 
 /* Replaces sim.addObstacle + sim.processObstacles (env.py:118-123, 143-149): the same polygons
- * for every arena.  verts_xy: host array [sum(poly_sizes), 2].  Like the RVO2 library's
+ * for every arena (see ca_set_obstacles_per_arena for a world per arena).  verts_xy: host array [sum(poly_sizes), 2].  Like the RVO2 library's
  * processObstacles, edges that cross the supporting line of a splitting edge of its obstacle tree are cut
  * there; the cut points are appended to the vertex table behind the caller's vertices. */
 int ca_set_obstacles(ca_env* env, const float* verts_xy, const int32_t* poly_sizes, int32_t n_poly);
@@ -152,6 +156,15 @@ int ca_set_obstacles(ca_env* env, const float* verts_xy, const int32_t* poly_siz
  * vertex table.  Edge i runs from vertex i to vertex next[i]; these are the ids in CA_FLD_OBST_IDX.
  * Host arrays of capacity `cap` (each may be NULL); *n_out = number of vertices. */
 int ca_get_obstacles(ca_env* env, float* verts_xy, int32_t* next, int32_t* convex, int32_t cap, int32_t* n_out);
+/* A world of its own for every arena: the reference builds a simulator per environment and draws the four blocks of
+ * the "blocks" world anew for each (ALAN:359-372: addObstacle x 5 + processObstacles per simulator; reset() redraws
+ * them, ALAN:92-100; the trainer averages over such worlds, Train_ALAN_action_space.py:53-66).
+ * n_poly: host array [A], polygons of arena a; poly_sizes / verts_xy: all arenas' polygons back to back.
+ * Each arena gets its own processed table; obstacle-neighbour ids (CA_FLD_OBST_IDX) are local to it. */
+int ca_set_obstacles_per_arena(ca_env* env, const float* verts_xy, const int32_t* poly_sizes, const int32_t* n_poly);
+/* ca_get_obstacles for the table of one arena (the common table if ca_set_obstacles installed one). */
+int ca_get_obstacles_arena(ca_env* env, int32_t arena, float* verts_xy, int32_t* next, int32_t* convex, int32_t cap,
+                           int32_t* n_out);
 
 /* Replaces _init_world's agent loop (env.py:86-97) / ALAN's scenario generators (ALAN:270-330). */
 int ca_init_scenario(ca_env* env, int32_t scenario);

@@ -331,8 +331,9 @@ def test_full_size_properties(name, A, N, nd, K, steps):
     assert cnt.max() <= K and cnt.min() >= 0
     px, py = env.get(_lib.FLD_POS_X), env.get(_lib.FLD_POS_Y)
     a = np.arange(A)[:, None, None]
-    d = np.hypot(px[a, idx.clip(0)] - px[:, :, None], py[a, idx.clip(0)] - py[:, :, None])
     valid = np.arange(K)[None, None, :] < cnt[:, :, None]
+    idx = np.where(valid, idx, 0)                                              # entries beyond the count are unspecified
+    d = np.hypot(px[a, idx] - px[:, :, None], py[a, idx] - py[:, :, None])
     assert not np.any(valid & (idx == np.arange(N)[None, :, None]))            # never itself
     assert np.all((idx >= 0) | ~valid) and np.all((idx < N) | ~valid)
     # lists are those of the last doStep (pre-update positions); both agents moved <= maxSpeed*dt since
