@@ -54,7 +54,9 @@ def save_actions(path, actions):
 def evaluate_actions(actions, numAgents=50, scenario="crowd", num=3, mode=1, device=0, seed=0):
     """Mean TTime of an action set over `num` random worlds -- what MCMC_trainer.evaluate_action
     (Train_ALAN_action_space.py:53-66) computes with `num` reset()/run_sim() rounds in sequence -- as ONE
-    batched run: the `num` episodes are the arenas of one handle.  Returns (mean TTime, successes)."""
+    batched run: the `num` episodes are the arenas of one handle, each arena a world of its own (in the "blocks"
+    scenario every arena draws its own four blocks, like every reset() of the reference, ALAN_true.py:92-100, 359-372).
+    Returns (mean TTime, successes)."""
     sim = Collision_Avoidance_Sim(numAgents=numAgents, scenario=scenario, online_actions=actions, device=device,
                                   seed=seed, n_arenas=num)
     ok, _, tt, _ = sim.run_sim(mode)

@@ -49,8 +49,8 @@ def envsize(scenario, n_agents, radius=0.5):
 
 
 def obstacles(scenario, n_agents, radius=0.5, seed=0):
-    """Obstacle polygons of a scenario as lists of (x, y).  `seed` places the four random blocks of the
-    "blocks" scenario (ALAN:364-372; the same layout for every arena of a handle)."""
+    """Obstacle polygons of a scenario as lists of (x, y).  For "blocks" this is ONE layout (numpy RandomState(seed));
+    a batch draws a layout per arena instead: obstacle_worlds() / blocks_worlds()."""
     scenario = SCENARIO_NAMES.get(scenario, scenario)
     r = radius
     if scenario == "crowd_separated":
@@ -95,6 +95,70 @@ def obstacles(scenario, n_agents, radius=0.5, seed=0):
                 _rect((2.0, 0.0), (2.5, 0.0), (2.5, 4.4), (2.0, 4.4)),   # env.py:121
                 _rect((2.0, 5.6), (2.5, 5.6), (2.5, 10.0), (2.0, 10.0))]  # env.py:122
     raise ValueError("unknown scenario %r" % (scenario,))
+
+
+# ---- counter-based draws on the host (the library's stream: Philox4x32-10 keyed by (seed, global arena id)) ----
+RNG_BLOCKS = 6   # purpose word of the block-position draws (csrc/ca_math.h: RNG_POS .. RNG_ALAN are 0..5)
+
+
+def _philox4x32(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 on numpy uint64 arrays holding 32-bit words (same rounds and constants as csrc/ca_math.h)."""
+    import numpy as np
+    m32 = np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3, k0, k1 = (np.asarray(v, np.uint64) & m32 for v in (c0, c1, c2, c3, k0, k1))
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        h0, l0, h1, l1 = p0 >> np.uint64(32), p0 & m32, p1 >> np.uint64(32), p1 & m32
+        c0, c1, c2, c3 = h1 ^ c1 ^ k0, l1, h0 ^ c3 ^ k1, l0
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return c0, c1, c2, c3
+
+
+def rng2(seed, arena, agent, purpose, seq=0):
+    """Two uniforms in [0, 1) with 53 random bits each: the library's rng2 (csrc/ca_math.h), vectorised over
+    `arena` (global arena ids)."""
+    import numpy as np
+    g = np.asarray(arena, np.int64).astype(np.uint64)
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    k1 = (np.uint64(seed >> 32) + (g >> np.uint64(32))) & np.uint64(0xFFFFFFFF)
+    w = _philox4x32(g & np.uint64(0xFFFFFFFF), np.uint64(agent), np.uint64(purpose), np.uint64(seq),
+                    np.uint64(seed & 0xFFFFFFFF), k1)
+    k = 1.0 / 9007199254740992.0
+    u0 = (((w[0] >> np.uint64(5)) << np.uint64(26)) | (w[1] >> np.uint64(6))).astype(np.float64) * k
+    u1 = (((w[2] >> np.uint64(5)) << np.uint64(26)) | (w[3] >> np.uint64(6))).astype(np.float64) * k
+    return u0, u1
+
+
+def blocks_worlds(n_arenas, n_agents, radius=0.5, seed=0, arena_offset=0):
+    """The "blocks" world of every arena: the border and FOUR RANDOM BLOCKS PER ARENA, as every simulator of the
+    reference draws its own (ALAN:359-372; reset() redraws them, ALAN:92-100).  Block k of global arena g sits
+    at (uniform(b, E - b), uniform(0, E)) with the uniforms rng2(seed, g, k, RNG_BLOCKS): keyed by the GLOBAL
+    arena id, so the worlds do not depend on how arenas are sharded over GPUs."""
+    import numpy as np
+    e = envsize("blocks", n_agents, radius)
+    b = e / (4 * 2)
+    g = np.arange(n_arenas, dtype=np.int64) + int(arena_offset)
+    draws = [rng2(seed, g, k, RNG_BLOCKS) for k in range(4)]
+    worlds = []
+    for a in range(n_arenas):
+        polys = [_rect((0.0, 0.0), (0.0, e), (e, e), (e, 0.0))]
+        for k in range(4):
+            x = b + ((e - b) - b) * float(draws[k][0][a])
+            y = 0.0 + (e - 0.0) * float(draws[k][1][a])
+            polys.append(_rect((x - b / 2, y - b / 2), (x + b / 2, y - b / 2), (x + b / 2, y + b / 2), (x - b / 2, y + b / 2)))
+        worlds.append(polys)
+    return worlds
+
+
+def obstacle_worlds(scenario, n_arenas, n_agents, radius=0.5, seed=0, arena_offset=0):
+    """None when every arena of the scenario has the same obstacles (use obstacles()), else the list of per-arena
+    polygon lists (only "blocks" draws its world at random)."""
+    scenario = SCENARIO_NAMES.get(scenario, scenario)
+    if scenario == "blocks":
+        return blocks_worlds(n_arenas, n_agents, radius, seed, arena_offset)
+    return None
 
 
 def env_params():

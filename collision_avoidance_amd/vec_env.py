@@ -45,11 +45,16 @@ class VecCollisionAvoidanceEnv:
         p = scenarios.env_params()
         if params:
             p.update(params)
+        worlds = None   # a world per arena (list of polygon lists) or None: the same polygons for every arena
         if obstacles == "scenario":
-            polys = scenarios.obstacles(scenario, n_agents, p["radius"]) if scenario is not None else []
+            worlds = scenarios.obstacle_worlds(scenario, self.A, n_agents, p["radius"], seed, arena_offset) \
+                if scenario is not None else None
+            polys = scenarios.obstacles(scenario, n_agents, p["radius"]) if scenario is not None and worlds is None else []
+        elif isinstance(obstacles, dict) and "per_arena" in obstacles:
+            worlds, polys = list(obstacles["per_arena"]), []
         else:
             polys = list(obstacles or [])
-        n_edges = sum(len(q) for q in polys)
+        n_edges = max(sum(len(q) for q in w) for w in worlds) if worlds else sum(len(q) for q in polys)
         if max_obst_neighbors is None:
             max_obst_neighbors = max(1, min(_lib.MAX_OBST_NEIGHBORS, n_edges))
         self.cfg = _lib.Config(n_arenas=self.A, n_agents=self.N, arena_offset=arena_offset, seed=seed,
@@ -75,7 +80,10 @@ class VecCollisionAvoidanceEnv:
             self._rew_t = self.field_tensor(_lib.FLD_REWARD)        # views of the library's own buffers: no copies
             self._done_t = self.field_tensor(_lib.FLD_ARENA_DONE)
             self._act_t = torch.zeros((self.A, self.N), dtype=torch.float32, device=dev)
-        self.set_obstacles(polys)
+        if worlds is not None:
+            self.set_obstacles_per_arena(worlds)
+        else:
+            self.set_obstacles(polys)
         if scenario is not None:
             self.init_scenario(scenario)
 
@@ -158,13 +166,24 @@ class VecCollisionAvoidanceEnv:
         sizes = np.asarray([len(q) for q in polys], np.int32)
         self._call("ca_set_obstacles", self.h, _ptr(verts), _ptr(sizes), len(polys))
 
-    def obstacle_table(self):
-        """The processed vertex table (after the edge cuts of processObstacles): dict(verts [n,2], next [n],
-        convex [n]); edge i = verts[i] -> verts[next[i]], the ids of obstacle_neighbor_lists()."""
+    def set_obstacles_per_arena(self, worlds):
+        """A world of its own for every arena (the reference builds one simulator per environment and draws e.g. the
+        blocks of ALAN_true.py:359-372 anew for each): worlds[a] = list of polygons of arena a."""
+        if len(worlds) != self.A:
+            raise ValueError("set_obstacles_per_arena: %d worlds for %d arenas" % (len(worlds), self.A))
+        polys = [np.asarray(q, np.float32).reshape(-1, 2) for w in worlds for q in w]
+        verts = np.ascontiguousarray(np.concatenate(polys) if polys else np.zeros((0, 2), np.float32))
+        sizes = np.asarray([len(q) for q in polys], np.int32)
+        counts = np.asarray([len(w) for w in worlds], np.int32)
+        self._call("ca_set_obstacles_per_arena", self.h, _ptr(verts), _ptr(sizes), _ptr(counts))
+
+    def obstacle_table(self, arena=0):
+        """The processed vertex table of an arena (after the edge cuts of processObstacles): dict(verts [n,2],
+        next [n], convex [n]); edge i = verts[i] -> verts[next[i]], the ids of obstacle_neighbor_lists()."""
         n = C.c_int32()
-        self._call("ca_get_obstacles", self.h, None, None, None, 0, C.byref(n))
+        self._call("ca_get_obstacles_arena", self.h, int(arena), None, None, None, 0, C.byref(n))
         verts, nxt, cvx = np.zeros((n.value, 2), np.float32), np.zeros(n.value, np.int32), np.zeros(n.value, np.int32)
-        self._call("ca_get_obstacles", self.h, _ptr(verts), _ptr(nxt), _ptr(cvx), n.value, C.byref(n))
+        self._call("ca_get_obstacles_arena", self.h, int(arena), _ptr(verts), _ptr(nxt), _ptr(cvx), n.value, C.byref(n))
         return dict(verts=verts, next=nxt, convex=cvx)
 
     def init_scenario(self, scenario):

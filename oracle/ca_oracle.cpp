@@ -703,7 +703,10 @@ void comp_laser(const T* rays, const Seg<T>* segs, int m, T c, T s, T* out) {
 /* ------------------------------------------------------------------------------------------ */
 struct Env {
     orc_config cfg;
-    std::vector<ObstVertex> obst;
+    std::vector<ObstVertex> obst;                   /* the world every arena shares ...                    */
+    std::vector<std::vector<ObstVertex> > obst_a;   /* ... or one world per arena (ALAN:359-372: every simulator
+                                                       draws its own blocks); ids are local to the arena's table */
+    const std::vector<ObstVertex>& tab(int a) const { return obst_a.empty() ? obst : obst_a[a]; }
     std::vector<Arena> arenas;
     std::vector<double> goal_x, goal_y, goal2_x, goal2_y;  /* fp64 like the reference's target tuples */
     std::vector<float> reward, obs;
@@ -763,10 +766,11 @@ void agent_obs(Env& e, int a, int i, T* out) {
         }
     }
     for (size_t k = 0; k < ar.obstNb[i].size(); ++k) { /* env.py:305-315 */
-        const int v1 = ar.obstNb[i][k].second, v2 = e.obst[v1].next;
+        const std::vector<ObstVertex>& ob = e.tab(a);
+        const int v1 = ar.obstNb[i][k].second, v2 = ob[v1].next;
         Seg<T> g;
-        g.x1 = (T)e.obst[v1].p.x - (T)me.x; g.y1 = (T)e.obst[v1].p.y - (T)me.y;
-        g.x2 = (T)e.obst[v2].p.x - (T)me.x; g.y2 = (T)e.obst[v2].p.y - (T)me.y;
+        g.x1 = (T)ob[v1].p.x - (T)me.x; g.y1 = (T)ob[v1].p.y - (T)me.y;
+        g.x2 = (T)ob[v2].p.x - (T)me.x; g.y2 = (T)ob[v2].p.y - (T)me.y;
         g.vx = T(0); g.vy = T(0);
         segs.push_back(g);
     }
@@ -805,9 +809,10 @@ void arena_collisions(Env& e, int a) {
             if (absSq(ar.pos[i] - ar.pos[j]) < sqr(cr)) ++pairs;
         }
         bool hit = false;
-        for (size_t k = 0; k < e.obst.size(); ++k) {
-            const ObstVertex& o1 = e.obst[k];
-            if (distSqPointSegment(o1.p, e.obst[o1.next].p, ar.pos[i]) < sqr(ar.prm[i].radius)) hit = true;
+        const std::vector<ObstVertex>& ob = e.tab(a);
+        for (size_t k = 0; k < ob.size(); ++k) {
+            const ObstVertex& o1 = ob[k];
+            if (distSqPointSegment(o1.p, ob[o1.next].p, ar.pos[i]) < sqr(ar.prm[i].radius)) hit = true;
         }
         if (hit) ++walls;
     }
@@ -926,7 +931,7 @@ void arena_step(Env& e, int a, const float* actions, uint32_t flags, int prec) {
             ar.pref[i] = mk((float)lx, (float)ly);
         }
     }
-    do_step(ar, e.obst, c.time_step, c.max_obst_neighbors, &e.st[a].obst_overflow);
+    do_step(ar, e.tab(a), c.time_step, c.max_obst_neighbors, &e.st[a].obst_overflow);
     e.st[a].agent_steps += (uint64_t)N;
     if (flags & ORC_F_STATS) arena_collisions(e, a);
     if (actions) {
@@ -985,7 +990,7 @@ void arena_alan_step(Env& e, int a, const double* u, uint32_t flags, int prec) {
         e.rl64[2 * q] = lx; e.rl64[2 * q + 1] = ly;
         ar.pref[i] = mk((float)lx, (float)ly);                                        /* :598 */
     }
-    do_step(ar, e.obst, c.time_step, c.max_obst_neighbors, &e.st[a].obst_overflow);  /* :601 */
+    do_step(ar, e.tab(a), c.time_step, c.max_obst_neighbors, &e.st[a].obst_overflow);  /* :601 */
     e.st[a].agent_steps += (uint64_t)N;
     if (flags & ORC_F_STATS) arena_collisions(e, a);
     if (prec == ORC_PREC_F64) arena_reward<double>(e, a);
@@ -1073,6 +1078,7 @@ void orc_env_destroy(void* env) { delete (Env*)env; }
 int orc_env_set_obstacles(void* env, const float* verts_xy, const int32_t* poly_sizes, int32_t n_poly) {
     Env* e = (Env*)env;
     e->obst.clear();
+    e->obst_a.clear();
     size_t off = 0;
     for (int p = 0; p < n_poly; ++p) {
         if (add_polygon(e->obst, verts_xy + 2 * off, poly_sizes[p]) < 0) return -1;
@@ -1082,16 +1088,40 @@ int orc_env_set_obstacles(void* env, const float* verts_xy, const int32_t* poly_
     return 0;
 }
 
-int orc_env_obstacle_table(void* env, float* px, float* py, float* ux, float* uy, int32_t* next,
-                           int32_t* prev, int32_t* convex, int32_t cap) {
+/* a world per arena: n_poly[a] polygons for arena a, all polygons back to back (ALAN:359-372 per simulator) */
+int orc_env_set_obstacles_per_arena(void* env, const float* verts_xy, const int32_t* poly_sizes, const int32_t* n_poly) {
     Env* e = (Env*)env;
-    const int n = (int)e->obst.size();
+    e->obst.clear();
+    e->obst_a.assign(e->A(), std::vector<ObstVertex>());
+    size_t voff = 0, poff = 0;
+    for (int a = 0; a < e->A(); ++a) {
+        for (int p = 0; p < n_poly[a]; ++p) {
+            if (add_polygon(e->obst_a[a], verts_xy + 2 * voff, poly_sizes[poff]) < 0) return -1;
+            voff += poly_sizes[poff];
+            ++poff;
+        }
+        process_obstacles(e->obst_a[a]);
+    }
+    return 0;
+}
+
+static int table_out(const std::vector<ObstVertex>& ob, float* px, float* py, float* ux, float* uy, int32_t* next,
+                     int32_t* prev, int32_t* convex, int32_t cap) {
+    const int n = (int)ob.size();
     for (int i = 0; i < n && i < cap; ++i) {
-        px[i] = e->obst[i].p.x; py[i] = e->obst[i].p.y;
-        ux[i] = e->obst[i].unitDir.x; uy[i] = e->obst[i].unitDir.y;
-        next[i] = e->obst[i].next; prev[i] = e->obst[i].prev; convex[i] = e->obst[i].convex ? 1 : 0;
+        px[i] = ob[i].p.x; py[i] = ob[i].p.y;
+        ux[i] = ob[i].unitDir.x; uy[i] = ob[i].unitDir.y;
+        next[i] = ob[i].next; prev[i] = ob[i].prev; convex[i] = ob[i].convex ? 1 : 0;
     }
     return n;
+}
+int orc_env_obstacle_table(void* env, float* px, float* py, float* ux, float* uy, int32_t* next,
+                           int32_t* prev, int32_t* convex, int32_t cap) {
+    return table_out(((Env*)env)->tab(0), px, py, ux, uy, next, prev, convex, cap);
+}
+int orc_env_obstacle_table_arena(void* env, int32_t arena, float* px, float* py, float* ux, float* uy, int32_t* next,
+                                 int32_t* prev, int32_t* convex, int32_t cap) {
+    return table_out(((Env*)env)->tab(arena), px, py, ux, uy, next, prev, convex, cap);
 }
 
 /* scenario generators: agents only (obstacles come through orc_env_set_obstacles) */

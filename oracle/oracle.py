@@ -70,6 +70,8 @@ def lib():
     L.orc_env_create.argtypes = [C.POINTER(Config)]
     L.orc_env_destroy.argtypes = [vp]
     L.orc_env_set_obstacles.argtypes = [vp, vp, vp, i32]
+    L.orc_env_set_obstacles_per_arena.argtypes = [vp, vp, vp, vp]
+    L.orc_env_obstacle_table_arena.argtypes = [vp, i32] + [vp] * 7 + [i32]
     L.orc_env_init_scenario.argtypes = [vp, i32]
     L.orc_env_set.argtypes = [vp, i32, vp, sz]
     L.orc_env_get.argtypes = [vp, i32, vp, sz]
@@ -177,11 +179,24 @@ class OracleEnv:
         rc = self.L.orc_env_set_obstacles(self.h, _ptr(verts), _ptr(sizes), len(polys))
         assert rc == 0
 
-    def obstacle_table(self, cap=256):
+    def set_obstacles_per_arena(self, worlds):
+        """worlds[a] = the polygons of arena a."""
+        assert len(worlds) == self.A
+        polys = [np.asarray(q, np.float32).reshape(-1, 2) for w in worlds for q in w]
+        verts = np.ascontiguousarray(np.concatenate(polys) if polys else np.zeros((0, 2), np.float32))
+        sizes = np.asarray([len(q) for q in polys], np.int32)
+        counts = np.asarray([len(w) for w in worlds], np.int32)
+        assert self.L.orc_env_set_obstacles_per_arena(self.h, _ptr(verts), _ptr(sizes), _ptr(counts)) == 0
+
+    def obstacle_table(self, cap=256, arena=None):
         px, py, ux, uy = (np.zeros(cap, np.float32) for _ in range(4))
         nx, pv, cv = (np.zeros(cap, np.int32) for _ in range(3))
-        n = self.L.orc_env_obstacle_table(self.h, _ptr(px), _ptr(py), _ptr(ux), _ptr(uy), _ptr(nx),
-                                          _ptr(pv), _ptr(cv), cap)
+        if arena is None:
+            n = self.L.orc_env_obstacle_table(self.h, _ptr(px), _ptr(py), _ptr(ux), _ptr(uy), _ptr(nx),
+                                              _ptr(pv), _ptr(cv), cap)
+        else:
+            n = self.L.orc_env_obstacle_table_arena(self.h, int(arena), _ptr(px), _ptr(py), _ptr(ux), _ptr(uy),
+                                                    _ptr(nx), _ptr(pv), _ptr(cv), cap)
         return dict(px=px[:n], py=py[:n], ux=ux[:n], uy=uy[:n], next=nx[:n], prev=pv[:n], convex=cv[:n])
 
     def init_scenario(self, scenario):

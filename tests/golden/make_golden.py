@@ -13,6 +13,9 @@ none of its source is copied: the fixtures hold inputs and the outputs the refer
                       stream.  Pins the env loop A5-A9, A16-A19.
   alan_scenarios.npz  ALAN_true.py scenario generators: start/goal layouts and obstacle polygons.
   alan_online.npz     ALAN_true.py online_step runs (softmax selection, weights, arrival times, TTime).
+  alan_orca.npz       ALAN_true.py run_sim(mode=0) episodes (orca_step + counter + done_test).
+  alan_blocks.npz     three "blocks" worlds as the reference draws them (ALAN_true.py:333-374: four random blocks per
+                      simulator, re-drawn by reset()), their polygons, and run_sim(mode=0) in each.
 
 Usage: python tests/golden/make_golden.py
 """
@@ -404,9 +407,63 @@ def gen_alan_orca():
                                                              [int(out["c%d_success" % i]) for i in range(len(cases))]))
 
 
+def gen_alan_blocks():
+    """Three random "blocks" worlds (ALAN_true.py:359-372 draws four blocks per simulator; reset() -- :92-100 -- draws
+    new ones) and the plain-ORCA episode of each: what a batch with one world per arena has to reproduce."""
+    import warnings
+    warnings.simplefilter("ignore")
+    import collision_avoidance.ALAN.ALAN_true as alan
+    out = {}
+    n = 12
+    alan.uniform = _Stream(4242)
+    sim = alan.Collision_Avoidance_Sim(numAgents=n, scenario="blocks", visualize=False)
+    for wi in range(3):
+        sim.reset(None)                                 # a new world from the same stream, like the trainer's rounds
+        key = "w%d_" % wi
+        out[key + "obst"] = np.array([[sim.sim.getObstacleVertex(v) for v in ids]
+                                      for ids in sim.world["obstacles_vertex_ids"]], np.float32)   # [5, 4, 2]
+        out[key + "pos0"] = np.array([sim.sim.getAgentPosition(i) for i in range(n)], np.float32)
+        out[key + "vel0"] = np.array([sim.sim.getAgentVelocity(i) for i in range(n)], np.float32)
+        out[key + "goal0"] = np.array([sim.world["targets_pos"][i][0] for i in range(n)], np.float64)
+        out[key + "goal20"] = np.array([sim.world["targets_pos"][i][1] for i in range(n)], np.float64)
+        out[key + "pref0"] = np.array([sim.sim.getAgentPrefVelocity(i) for i in range(n)], np.float32)
+        rec = dict(pos=[], vel=[], done=[])
+        steps, success = 0, False
+        for s_ in range(min(sim.max_step, 1500)):      # the body of run_sim(0), recorded step by step
+            sim.orca_step()
+            sim.step_count += 1
+            success = sim.done_test()
+            steps += 1
+            rec["pos"].append([sim.sim.getAgentPosition(i) for i in range(n)])
+            rec["vel"].append([sim.sim.getAgentVelocity(i) for i in range(n)])
+            rec["done"].append(list(sim.agents_done))
+            if success:
+                break
+        out[key + "pos"] = np.array(rec["pos"], np.float32)[::5]
+        out[key + "vel"] = np.array(rec["vel"], np.float32)[::5]
+        out[key + "pos_last"] = np.array(rec["pos"][-1], np.float32)
+        out[key + "done"] = np.array(rec["done"], np.int32)[::5]
+        out[key + "done_last"] = np.array(rec["done"][-1], np.int32)
+        out[key + "steps"] = np.int32(steps)
+        out[key + "success"] = np.int32(bool(success))
+        out[key + "agents_time"] = np.array(sim.agents_time, np.float64)
+        out[key + "max_step"] = np.int32(sim.max_step)
+        out[key + "n_obst_vertices"] = np.int32(sim.sim.getNumObstacleVertices()) if hasattr(sim.sim, "getNumObstacleVertices") else np.int32(-1)
+    out["n_worlds"] = np.int32(3)
+    out["n_agents"] = np.int32(n)
+    np.savez_compressed(os.path.join(HERE, "alan_blocks.npz"), **out)
+    print("alan_blocks.npz: steps %s, success %s, block 0 of each world at %s" % (
+        [int(out["w%d_steps" % i]) for i in range(3)], [int(out["w%d_success" % i]) for i in range(3)],
+        [out["w%d_obst" % i][1][0].tolist() for i in range(3)]))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "blocks":   # only the file added in round 2
+        install_stubs()
+        gen_alan_blocks()
         sys.exit(0)
     gen_utils_vectors()
     install_stubs()
@@ -416,3 +473,4 @@ if __name__ == "__main__":
     gen_alan_scenarios()
     gen_alan_online()
     gen_alan_orca()
+    gen_alan_blocks()

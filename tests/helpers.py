@@ -20,13 +20,23 @@ def scenario_params(scenario, n_agents, **over):
 
 
 def make_oracle(A, N, scenario, params, seed=0, arena_offset=0, max_obst_neighbors=None, polys=None):
-    polys = scenarios.obstacles(scenario, N, params["radius"]) if polys is None else polys
-    n_edges = sum(len(q) for q in polys)
+    """polys: None = the scenario's own obstacles (a world per arena where the scenario draws them at random),
+    a list of polygons = the same for every arena, dict(per_arena=[...]) = explicit per-arena worlds."""
+    worlds = None
+    if polys is None:
+        worlds = scenarios.obstacle_worlds(scenario, A, N, params["radius"], seed, arena_offset)
+        polys = scenarios.obstacles(scenario, N, params["radius"]) if worlds is None else []
+    elif isinstance(polys, dict):
+        worlds, polys = list(polys["per_arena"]), []
+    n_edges = max(sum(len(q) for q in w) for w in worlds) if worlds else sum(len(q) for q in polys)
     S = max(1, min(8, n_edges)) if max_obst_neighbors is None else max_obst_neighbors
     cfg = o.make_config(n_arenas=A, n_agents=N, seed=seed, arena_offset=arena_offset,
                         max_obst_neighbors=S, **params)
     env = o.OracleEnv(cfg)
-    env.set_obstacles(polys)
+    if worlds is not None:
+        env.set_obstacles_per_arena(worlds)
+    else:
+        env.set_obstacles(polys)
     env.init_scenario(SCN[scenario])
     return env
 

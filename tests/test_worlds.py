@@ -1,0 +1,214 @@
+"""A world per arena: the reference builds one simulator per environment and
+draws the four blocks of the "blocks" scenario anew for each (ALAN_true.py:359-372), reset() redraws them
+(:92-100) and the trainer averages over such worlds (Train_ALAN_action_space.py:53-66).
+
+CPU part: the host-side Philox equals the oracle's; the oracle with one table per arena replays the three worlds of
+tests/golden/alan_blocks.npz (recorded from the reference's own _init_world_blocks / run_sim(0)) AS ONE BATCH.
+GPU part (marked): the HIP path does the same and matches the oracle on generated and hand-made per-arena worlds."""
+import os
+
+import numpy as np
+import pytest
+
+from collision_avoidance_amd import scenarios
+from oracle import oracle as o
+from tests import helpers as H
+
+
+def load_worlds(golden_dir):
+    g = np.load(os.path.join(golden_dir, "alan_blocks.npz"))
+    W = int(g["n_worlds"])
+    return [{k[3:]: g[k] for k in g.files if k.startswith("w%d_" % w)} for w in range(W)], int(g["n_agents"])
+
+
+def test_host_philox_equals_oracle():
+    for g, i, p, s, seed in [(0, 0, 6, 0, 0), (5, 3, 6, 0, 12345678901234), (2 ** 33 + 7, 1, 6, 2, 99), (4095, 63, 0, 1, 2 ** 63 + 5)]:
+        u = scenarios.rng2(seed, np.array([g]), i, p, s)
+        w = o.philox4x32((g & 0xffffffff, i, p, s), (seed & 0xffffffff, ((seed >> 32) + (g >> 32)) & 0xffffffff))
+        assert u[0][0] == (((w[0] >> 5) << 26) | (w[1] >> 6)) * 2.0 ** -53
+        assert u[1][0] == (((w[2] >> 5) << 26) | (w[3] >> 6)) * 2.0 ** -53
+
+
+def test_blocks_worlds_are_keyed_by_global_arena():
+    e = scenarios.envsize("blocks", 12)
+    whole = scenarios.blocks_worlds(6, 12, seed=9)
+    parts = scenarios.blocks_worlds(2, 12, seed=9, arena_offset=0) + scenarios.blocks_worlds(4, 12, seed=9, arena_offset=2)
+    assert whole == parts                                                  # sharding does not change the worlds
+    assert len({tuple(w[1][0]) for w in whole}) == 6                       # every arena its own blocks
+    b = e / 8
+    for w in whole:
+        assert len(w) == 5 and w[0] == [(0.0, 0.0), (0.0, e), (e, e), (e, 0.0)]          # ALAN:359-360
+        for blk in w[1:]:
+            cx, cy = blk[0][0] + b / 2, blk[0][1] + b / 2
+            assert b <= cx <= e - b and 0 <= cy <= e                        # ALAN:366-367
+            assert abs(blk[2][0] - blk[0][0] - b) < 1e-12 and abs(blk[2][1] - blk[0][1] - b) < 1e-12
+
+
+def batch_of_golden_worlds(make, worlds, n, set_field, F):
+    """One batch whose arena w is golden world w: per-arena obstacle polygons, initial state of each world."""
+    p = scenarios.alan_params(n, "blocks")
+    env = make(len(worlds), n, p, [[q.tolist() for q in w["obst"]] for w in worlds])
+    stack = lambda k, c: np.stack([w[k][:, c] for w in worlds])
+    for f, k, c in ((F.FLD_POS_X, "pos0", 0), (F.FLD_POS_Y, "pos0", 1), (F.FLD_VEL_X, "vel0", 0), (F.FLD_VEL_Y, "vel0", 1),
+                    (F.FLD_GOAL_X, "goal0", 0), (F.FLD_GOAL_Y, "goal0", 1), (F.FLD_GOAL2_X, "goal20", 0),
+                    (F.FLD_GOAL2_Y, "goal20", 1), (F.FLD_PREF_X, "pref0", 0), (F.FLD_PREF_Y, "pref0", 1)):
+        set_field(env, f, stack(k, c))
+    return env, p
+
+
+def replay_worlds(env, worlds, step, get, F):
+    steps = max(int(w["steps"]) for w in worlds)
+    for s in range(steps):
+        step(env)
+        if s % 5 == 0:
+            px, py, vx, dn = get(env, F.FLD_POS_X), get(env, F.FLD_POS_Y), get(env, F.FLD_VEL_X), get(env, F.FLD_AGENT_DONE)
+            for a, w in enumerate(worlds):
+                if s < int(w["steps"]):
+                    np.testing.assert_array_equal(px[a], w["pos"][s // 5][:, 0], err_msg="world %d step %d" % (a, s))
+                    np.testing.assert_array_equal(py[a], w["pos"][s // 5][:, 1])
+                    np.testing.assert_array_equal(vx[a], w["vel"][s // 5][:, 0])
+                    np.testing.assert_array_equal(dn[a], w["done"][s // 5])
+    for a, w in enumerate(worlds):
+        if int(w["steps"]) == steps:
+            np.testing.assert_array_equal(get(env, F.FLD_POS_X)[a], w["pos_last"][:, 0])
+            np.testing.assert_array_equal(get(env, F.FLD_AGENT_DONE)[a], w["done_last"])
+
+
+def test_oracle_replays_reference_block_worlds_as_one_batch(golden_dir):
+    worlds, n = load_worlds(golden_dir)
+    assert len({tuple(w["obst"][1].ravel()) for w in worlds}) == len(worlds)     # the reference drew different blocks
+
+    def make(A, n, p, polys):
+        e = o.OracleEnv(o.make_config(n_arenas=A, n_agents=n, max_obst_neighbors=8, **p))
+        e.set_obstacles_per_arena(polys)
+        e.init_scenario(o.SCN_BLOCKS)
+        return e
+    env, p = batch_of_golden_worlds(make, worlds, n, lambda e, f, v: e.set(f, v), o)
+    for a, w in enumerate(worlds):   # processObstacles leaves these worlds uncut: the table is the 20 input vertices
+        t = env.obstacle_table(arena=a)
+        np.testing.assert_array_equal(np.stack([t["px"], t["py"]], -1)[:20], w["obst"].reshape(20, 2))
+    replay_worlds(env, worlds, lambda e: e.orca_step(flags=o.F_FREEZE), lambda e, f: e.get(f), o)
+
+
+def test_oracle_per_arena_tables_equal_single_arena_runs():
+    """Arena a of a batch of generated worlds == the same world run alone (the tables do not leak into each other)."""
+    A, N = 5, 12
+    p = H.scenario_params("blocks", N)
+    batch = H.make_oracle(A, N, "blocks", p, seed=3)
+    batch.rollout(300, flags=o.F_STATS)
+    for a in range(A):
+        one = H.make_oracle(1, N, "blocks", p, seed=3, arena_offset=a)
+        one.rollout(300, flags=o.F_STATS)
+        for f in (o.FLD_POS_X, o.FLD_POS_Y, o.FLD_VEL_X, o.FLD_OBST_COUNT, o.FLD_OBST_IDX):
+            np.testing.assert_array_equal(batch.get(f)[a], one.get(f)[0])
+        ta, t1 = batch.obstacle_table(arena=a), one.obstacle_table()
+        for k in ta:
+            np.testing.assert_array_equal(ta[k], t1[k])
+    assert len({tuple(batch.obstacle_table(arena=a)["px"][4:8]) for a in range(A)}) == A
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_per_arena_obstacle_golden_worlds_on_gpu(golden_dir):
+    from collision_avoidance_amd import _lib
+    worlds, n = load_worlds(golden_dir)
+
+    def make(A, n, p, polys):
+        return H.make_gpu(A, n, "blocks", p, max_obst_neighbors=8, polys=dict(per_arena=polys))
+    env, p = batch_of_golden_worlds(make, worlds, n, lambda e, f, v: e.set(f, v), _lib)
+    for a, w in enumerate(worlds):
+        np.testing.assert_array_equal(env.obstacle_table(arena=a)["verts"][:20], w["obst"].reshape(20, 2))
+    replay_worlds(env, worlds, lambda e: e.orca_step(freeze=True), lambda e, f: e.get(f), _lib)
+    env.close()
+
+
+def _squares(k, x0, y0, pitch, size):
+    return [[(x0 + c * pitch, y0 + r * pitch), (x0 + c * pitch + size, y0 + r * pitch),
+             (x0 + c * pitch + size, y0 + r * pitch + size), (x0 + c * pitch, y0 + r * pitch + size)]
+            for r in range(k) for c in range(k)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,A,N,over,steps", [
+    ("blocks12", 6, 12, dict(), 400),                       # generated worlds (one per arena), ALAN parameters
+    ("blocks16x4", 9, 16, dict(), 300),                     # four arenas per wave, each with its own table
+    ("blocks3", 7, 3, dict(), 200),                         # sixteen arenas per wave, ragged last wave
+    ("blocks200", 2, 200, dict(), 60),                      # one arena per workgroup (grid scan), 12 edges... per arena
+])
+def test_per_arena_obstacle_worlds_match_oracle(name, A, N, over, steps):
+    from collision_avoidance_amd import _lib
+    p = H.scenario_params("blocks", N, **over)
+    g = H.make_gpu(A, N, "blocks", p, seed=5)
+    e = H.make_oracle(A, N, "blocks", p, seed=5)
+    for a in range(A):
+        tg, te = g.obstacle_table(arena=a), e.obstacle_table(arena=a)
+        np.testing.assert_array_equal(tg["verts"], np.stack([te["px"], te["py"]], -1))
+        np.testing.assert_array_equal(tg["next"], te["next"]); np.testing.assert_array_equal(tg["convex"], te["convex"])
+    rng = np.random.RandomState(2)
+    for s in range(steps):
+        if s % 3 == 2:
+            act = rng.uniform(-1, 1, (A, N)).astype(np.float32)
+            g.step(act, stats=True); e.step(act, flags=o.F_OBS | o.F_STATS)
+        else:
+            g.orca_step(with_obs=True, stats=True); e.orca_step(flags=o.F_OBS | o.F_STATS)
+        if s % 50 == 49 or s < 3:
+            H.assert_state_equal(g, e, "%s step %d" % (name, s), obs=True)
+    H.assert_state_equal(g, e, name + " end", obs=True)
+    H.assert_stats_equal(g, e, name)
+    assert g.stats()["obst_collisions"] >= 0 and (g.get(_lib.FLD_OBST_COUNT) > 0).any()
+    g.close()
+
+
+@pytest.mark.gpu
+def test_per_arena_obstacle_ragged_and_wide_tables():
+    """Worlds of different sizes in one batch: no obstacle at all, the plain border, a doorway-like world whose edges
+    processObstacles cuts, and a grid of 81 small squares (324 edges: ids no longer fit a byte, the lists switch to
+    16 bits); then a common table again through ca_set_obstacles."""
+    from collision_avoidance_amd import _lib
+    N = 10
+    p = H.scenario_params("crowd", N)
+    E = scenarios.envsize("crowd", N)
+    border = [(0.0, 0.0), (0.0, E), (E, E), (E, 0.0)]
+    worlds = [[], [border],
+              [border, [(2.0, 0.0), (2.5, 0.0), (2.5, 2.4), (2.0, 2.4)], [(2.0, 3.6), (2.5, 3.6), (2.5, E), (2.0, E)]],
+              [border] + _squares(9, 0.3, 0.3, 0.65, 0.2)]
+    g = H.make_gpu(4, N, "crowd", p, seed=8, polys=dict(per_arena=worlds), max_obst_neighbors=8)
+    e = H.make_oracle(4, N, "crowd", p, seed=8, polys=dict(per_arena=worlds), max_obst_neighbors=8)
+    assert [g.obstacle_table(arena=a)["verts"].shape[0] for a in range(4)][:2] == [0, 4]
+    assert g.obstacle_table(arena=3)["verts"].shape[0] >= 4 + 81 * 4
+    for a in range(4):
+        np.testing.assert_array_equal(g.obstacle_table(arena=a)["next"], e.obstacle_table(cap=1024, arena=a)["next"])
+    for s in range(250):
+        g.orca_step(with_obs=True, stats=True); e.orca_step(flags=o.F_OBS | o.F_STATS)
+        if s % 50 == 49:
+            H.assert_state_equal(g, e, "ragged worlds step %d" % s, obs=True)
+    H.assert_stats_equal(g, e, "ragged worlds")
+    assert g.get(_lib.FLD_OBST_IDX).max() > 255          # ids beyond a byte were stored and read back
+    g.set_obstacles([border]); e.set_obstacles([border])  # back to one table for every arena (8-bit ids again)
+    for s in range(60):
+        g.orca_step(with_obs=True, stats=True); e.orca_step(flags=o.F_OBS | o.F_STATS)
+    H.assert_state_equal(g, e, "common table again", obs=True)
+    g.close()
+
+
+@pytest.mark.gpu
+def test_per_arena_obstacle_trainer_evaluation_over_random_block_worlds():
+    """MCMC_trainer.evaluate_action (Train_ALAN_action_space.py:53-66): `num` rounds of reset() -- a NEW blocks world
+    each (ALAN_true.py:92-100, 359-372) -- and run_sim(); here the rounds are the arenas of one handle, each with its
+    own four random blocks, and equal the same rounds run one after the other."""
+    from collision_avoidance_amd import alan
+    acts = [(1, 0), (0.6, -0.8), (-0.5, 0.86)]
+    mean_tt, ok = alan.evaluate_actions(acts, numAgents=8, scenario="blocks", num=3, seed=11)
+    seq = alan.Collision_Avoidance_Sim(numAgents=8, scenario="blocks", online_actions=acts, seed=11)
+    tts, tabs = [], []
+    for r in range(3):
+        if r:
+            seq.reset(acts)
+        tabs.append(seq.vec.obstacle_table()["verts"].copy())
+        tts.append(seq.run_sim(1)[2])
+    assert abs(mean_tt - float(np.mean(tts))) < 1e-12 and 0 <= ok <= 3
+    assert not np.array_equal(tabs[0], tabs[1]) and not np.array_equal(tabs[1], tabs[2])      # reset() drew new blocks
+    batch = alan.Collision_Avoidance_Sim(numAgents=8, scenario="blocks", online_actions=acts, seed=11, n_arenas=3)
+    for r in range(3):
+        np.testing.assert_array_equal(batch.vec.obstacle_table(arena=r)["verts"], tabs[r])
+    batch.vec.close(); seq.vec.close()
