@@ -21,8 +21,8 @@ struct AlanArgs {
     double *w, *t;        // [A][nA][N] action weights / time since the action's weight was set
     int* action;          // [A*N] the action of the current step (complemented while its arena sits out a step)
     double* dirs;         // [4][A*N] goal direction and rotated direction of the current step
-    const double* u;      // [A*N] caller-supplied uniforms in [0,1), or null: Philox (RNG_ALAN, step)
-    const int *step_count, *arena_done;
+    const double* u;      // [A*N] caller-supplied uniforms in [0,1), or null: Philox (RNG_ALAN, episode, step)
+    const int *step_count, *arena_done, *episode;
     unsigned long long* arena_stats;
     double act_c[ALAN_MAX_ACTIONS], act_s[ALAN_MAX_ACTIONS];  // (cos, sin) of every action's angle
     double temp, window, dt, reward_scale;
@@ -75,7 +75,10 @@ __global__ __launch_bounds__(ALAN_BS) void alan_select_kernel(const AlanArgs p) 
     // np.random.choice(n, 1, p=ps) (ALAN:585): cdf = cumsum(p) / cdf[-1]; searchsorted(cdf, u, 'right')
     double ui;
     if (p.u) ui = p.u[q];
-    else { double u1; rng2(p.seed, p.arena_offset + a, i, RNG_ALAN, (uint32_t)p.step_count[a], &ui, &u1); }
+    else {  // stream (seed, global arena, agent, RNG_ALAN + 256 x episode, step): a new stream every episode of the arena
+        double u1;
+        rng2(p.seed, p.arena_offset + a, i, RNG_ALAN + (p.episode[a] << 8), (uint32_t)p.step_count[a], &ui, &u1);
+    }
     int id = nA - 1;
     double run = 0.0;
     bool found = false;

@@ -994,7 +994,7 @@ int ca_alan_step(ca_env* e, const double* u, int32_t u_is_device, uint32_t flags
     p.pos_x = e->pos_x; p.pos_y = e->pos_y; p.vel_x = e->vel_x; p.vel_y = e->vel_y;
     p.goal_x = e->goal_x; p.goal_y = e->goal_y; p.pref_x = e->pref_x; p.pref_y = e->pref_y; p.reward = e->reward;
     p.w = e->alan_w; p.t = e->alan_t; p.action = e->alan_action; p.dirs = e->alan_dirs; p.u = u;
-    p.step_count = e->step_count; p.arena_done = e->arena_done; p.arena_stats = e->arena_stats;
+    p.step_count = e->step_count; p.arena_done = e->arena_done; p.episode = e->episode; p.arena_stats = e->arena_stats;
     memcpy(p.act_c, e->act_c, sizeof p.act_c);
     memcpy(p.act_s, e->act_s, sizeof p.act_s);
     p.temp = e->alan_temp; p.window = e->alan_window; p.dt = e->alan_dt; p.reward_scale = c.reward_scale;

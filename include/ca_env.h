@@ -210,7 +210,7 @@ int ca_rollout(ca_env* env, int32_t steps, uint32_t flags);
  * ca_alan_step: softmax draw -> preferred velocity -> ORCA step -> reward -> bandit update -> step
  * counter -> goal test.  u: device or host array [A,N] f64 of uniforms in [0,1) that drive the draws (one per
  * agent, consumed like numpy's choice: first action whose normalised cdf exceeds u), or NULL to use
- * the handle's counter-based RNG keyed by (seed, global arena, agent, step).  Flags: CA_F_OBS,
+ * the handle's counter-based RNG keyed by (seed, global arena, agent, episode of the arena, step).  Flags: CA_F_OBS,
  * CA_F_STATS, CA_F_FREEZE. */
 int ca_alan_configure(ca_env* env, const double* actions_xy, int32_t n_actions, double temp, double timewindow,
                       double time_step);

@@ -668,8 +668,35 @@ struct Seg {
 
 /* utils.py:42-113.  (c, s) = (cos th, sin th), th = -atan2(orientation).  Ties between equal
  * distances resolve to the first segment (the reference's argsort is unspecified on ties). */
+/* How close a ray's answer is to flipping under rounding (test diagnostic, not part of the reference): for every
+ * segment the distance of its (s, t) = (s_numer, t_numer) / denom from the boundary of the accepted square [0,1]^2
+ * (utils.py:21-31), and the gap between the two nearest accepted hits relative to the ray length; the minimum. */
 template <class T>
-void comp_laser(const T* rays, const Seg<T>* segs, int m, T c, T s, T* out) {
+inline T ray_flip_margin(T rx, T ry, const Seg<T>* rot, int m) {
+    T margin = std::numeric_limits<T>::infinity(), d1 = margin, d2 = margin;
+    const T len = std::sqrt(rx * rx + ry * ry);
+    for (int k = 0; k < m; ++k) {
+        const T s32x = rot[k].x2 - rot[k].x1, s32y = rot[k].y2 - rot[k].y1;
+        const T denom = rx * s32y - s32x * ry;
+        if (denom == T(0)) continue;
+        const T s02x = T(0) - rot[k].x1, s02y = T(0) - rot[k].y1;
+        const T sp = (rx * s02y - ry * s02x) / denom, tp = (s32x * s02y - s32y * s02x) / denom;
+        const T es = std::max(std::max(-sp, sp - T(1)), T(0)), et = std::max(std::max(-tp, tp - T(1)), T(0));
+        T b;
+        if (es > T(0) || et > T(0)) b = std::max(es, et);                       /* outside: distance to the square */
+        else b = std::min(std::min(sp, T(1) - sp), std::min(tp, T(1) - tp));    /* inside: distance to its boundary */
+        margin = std::min(margin, b);
+        if (es == T(0) && et == T(0)) {
+            const T d = tp * len;
+            if (d < d1) { d2 = d1; d1 = d; } else if (d < d2) d2 = d;
+        }
+    }
+    if (d2 < std::numeric_limits<T>::infinity()) margin = std::min(margin, (d2 - d1) / len);
+    return margin;
+}
+
+template <class T>
+void comp_laser(const T* rays, const Seg<T>* segs, int m, T c, T s, T* out, double* margin = nullptr) {
     std::vector<Seg<T> > rot(m);
     for (int k = 0; k < m; ++k) {
         const Seg<T>& g = segs[k];
@@ -695,6 +722,7 @@ void comp_laser(const T* rays, const Seg<T>* segs, int m, T c, T s, T* out) {
         T vx = T(0), vy = T(0);
         if (bi >= 0 && !(bx == T(0) && by == T(0))) { vx = rot[bi].vx; vy = rot[bi].vy; } /* utils.py:103 */
         out[4 * i] = bx; out[4 * i + 1] = by; out[4 * i + 2] = vx; out[4 * i + 3] = vy;
+        if (margin) margin[i] = (double)ray_flip_margin<T>(rays[2 * i], rays[2 * i + 1], rot.data(), m);
     }
 }
 
@@ -711,6 +739,7 @@ struct Env {
     std::vector<double> goal_x, goal_y, goal2_x, goal2_y;  /* fp64 like the reference's target tuples */
     std::vector<float> reward, obs;
     std::vector<double> reward64, obs64;
+    std::vector<double> obs_margin;   /* [A*N*16], ORC_PREC_F64 only: ray_flip_margin of every ray (test diagnostic) */
     std::vector<int32_t> agent_done, arrive_step, regoal_count;
     std::vector<int32_t> step_count, arena_done, episode;
     std::vector<double> rl64;   /* scratch: action-rotated preferred direction, [A*N*2] */
@@ -747,7 +776,7 @@ void set_pref_toward_goal(Env& e, int a) {
 
 /* env.py:231-318 (_get_obs, _obs_neighbor_agent_lines, _obs_obstacle_lines) for one agent */
 template <class T>
-void agent_obs(Env& e, int a, int i, T* out) {
+void agent_obs(Env& e, int a, int i, T* out, double* margin = nullptr) {
     Arena& ar = e.arenas[a];
     const int N = e.N();
     const T* oct = (sizeof(T) == 8) ? (const T*)(const void*)e.oct64 : (const T*)(const void*)e.oct32;
@@ -776,20 +805,22 @@ void agent_obs(Env& e, int a, int i, T* out) {
     }
     if (segs.empty()) { /* env.py:267 */
         for (int k = 0; k < ORC_OBS_DIM; ++k) out[k] = T(0);
+        if (margin) for (int k = 0; k < ORC_N_RAYS; ++k) margin[k] = std::numeric_limits<double>::infinity();
         return;
     }
     double ox, oy; /* env.py:236: orientation = comp_pref_vel (current position, current target) */
     pref_dir64(me.x, me.y, e.goal_x[a * N + i], e.goal_y[a * N + i], &ox, &oy);
     /* utils.py:48-51: th = -atan2(oy, ox); cos th = ox, sin th = -oy for a unit vector */
     const T c = (T)ox, s = (T)(-oy);
-    comp_laser<T>(rays, segs.data(), (int)segs.size(), c, s, out);
+    comp_laser<T>(rays, segs.data(), (int)segs.size(), c, s, out, margin);
 }
 
 void arena_obs(Env& e, int a, int prec) {
     const int N = e.N();
     for (int i = 0; i < N; ++i) {
         if (prec == ORC_PREC_F64) {
-            agent_obs<double>(e, a, i, &e.obs64[((size_t)a * N + i) * ORC_OBS_DIM]);
+            agent_obs<double>(e, a, i, &e.obs64[((size_t)a * N + i) * ORC_OBS_DIM],
+                              &e.obs_margin[((size_t)a * N + i) * ORC_N_RAYS]);
             for (int k = 0; k < ORC_OBS_DIM; ++k)
                 e.obs[((size_t)a * N + i) * ORC_OBS_DIM + k] = (float)e.obs64[((size_t)a * N + i) * ORC_OBS_DIM + k];
         } else {
@@ -978,7 +1009,10 @@ void arena_alan_step(Env& e, int a, const double* u, uint32_t flags, int prec) {
         for (int k = 0; k < nA; ++k) cdf[k] /= acc;
         double ui;
         if (u) ui = u[i];
-        else { double u1; rng2(c.seed, c.arena_offset + a, i, RNG_ALAN, (uint32_t)e.step_count[a], &ui, &u1); }
+        else { /* a new stream every episode of the arena */
+            double u1;
+            rng2(c.seed, c.arena_offset + a, i, RNG_ALAN + (e.episode[a] << 8), (uint32_t)e.step_count[a], &ui, &u1);
+        }
         int id = 0;
         while (id < nA - 1 && !(cdf[id] > ui)) ++id;
         e.alan_action[q] = id;
@@ -1064,6 +1098,7 @@ void* orc_env_create(const orc_config* cfg) {
     e->goal2_x.assign(A * N, 0); e->goal2_y.assign(A * N, 0);
     e->reward.assign(A * N, 0); e->reward64.assign(A * N, 0);
     e->obs.assign(A * N * ORC_OBS_DIM, 0); e->obs64.assign(A * N * ORC_OBS_DIM, 0);
+    e->obs_margin.assign(A * N * ORC_N_RAYS, std::numeric_limits<double>::infinity());
     e->agent_done.assign(A * N, 0); e->arrive_step.assign(A * N, -1); e->regoal_count.assign(A * N, 0);
     e->step_count.assign(A, 0); e->arena_done.assign(A, 0); e->episode.assign(A, 0);
     e->rl64.assign(A * N * 2, 0); e->pf64.assign(A * N * 2, 0);
@@ -1259,6 +1294,7 @@ static int env_access(Env* e, int field, const void* src, void* dst, size_t byte
         case ORC_FLD_REWARD64: return write ? -3 : copy_out(e->reward64, dst, bytes);
         case ORC_FLD_OBS: return write ? -3 : copy_out(e->obs, dst, bytes);
         case ORC_FLD_OBS64: return write ? -3 : copy_out(e->obs64, dst, bytes);
+        case ORC_FLD_OBS_MARGIN: return write ? -3 : copy_out(e->obs_margin, dst, bytes);
         case ORC_FLD_AGENT_DONE: return write ? copy_in(e->agent_done, src, bytes) : copy_out(e->agent_done, dst, bytes);
         case ORC_FLD_ARRIVE_STEP: return write ? copy_in(e->arrive_step, src, bytes) : copy_out(e->arrive_step, dst, bytes);
         case ORC_FLD_REGOAL_COUNT: return write ? copy_in(e->regoal_count, src, bytes) : copy_out(e->regoal_count, dst, bytes);

@@ -21,7 +21,8 @@ SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN
 (FLD_POS_X, FLD_POS_Y, FLD_VEL_X, FLD_VEL_Y, FLD_PREF_X, FLD_PREF_Y, FLD_GOAL_X, FLD_GOAL_Y,
  FLD_GOAL2_X, FLD_GOAL2_Y, FLD_REWARD, FLD_AGENT_DONE, FLD_ARRIVE_STEP, FLD_NB_COUNT, FLD_NB_IDX,
  FLD_OBST_COUNT, FLD_OBST_IDX, FLD_OBS, FLD_OBS64, FLD_REWARD64, FLD_STEP_COUNT, FLD_ARENA_DONE,
- FLD_EPISODE, FLD_REGOAL_COUNT, FLD_ALAN_WEIGHTS, FLD_ALAN_TIMES, FLD_ALAN_ACTION, FLD_ARENA_STATS) = range(28)
+ FLD_EPISODE, FLD_REGOAL_COUNT, FLD_ALAN_WEIGHTS, FLD_ALAN_TIMES, FLD_ALAN_ACTION, FLD_ARENA_STATS,
+ FLD_OBS_MARGIN) = range(29)
 
 
 class Config(C.Structure):
@@ -133,7 +134,7 @@ def make_config(**kw):
 
 _FIELD_SHAPES = {
     FLD_NB_IDX: ("K", np.int32), FLD_OBST_IDX: ("S", np.int32), FLD_OBS: (OBS_DIM, np.float32),
-    FLD_OBS64: (OBS_DIM, np.float64), FLD_REWARD64: (None, np.float64),
+    FLD_OBS64: (OBS_DIM, np.float64), FLD_REWARD64: (None, np.float64), FLD_OBS_MARGIN: (16, np.float64),
     FLD_AGENT_DONE: (None, np.int32), FLD_ARRIVE_STEP: (None, np.int32),
     FLD_NB_COUNT: (None, np.int32), FLD_OBST_COUNT: (None, np.int32),
     FLD_REGOAL_COUNT: (None, np.int32), FLD_ALAN_ACTION: (None, np.int32),

@@ -220,3 +220,27 @@ def test_gpu_reproduces_reference_orca_episodes(golden_dir, ci):
     env.set(_lib.FLD_PREF_X, c["pref0"][:, 0]); env.set(_lib.FLD_PREF_Y, c["pref0"][:, 1])
     replay_orca_episode(env, c, _lib, lambda e: e.orca_step(), lambda e, f: e.get(f))
     env.close()
+
+
+def test_alan_draws_differ_between_episodes_of_an_arena():
+    """The built-in draw is keyed by the arena's episode counter as well as its step counter: two
+    consecutive episodes of the same arena, started from the same state, explore differently -- and still equal the
+    oracle."""
+    A, N = 3, 8
+    p = H.scenario_params("crowd", N)
+    g = H.make_gpu(A, N, "crowd", p, seed=9)
+    e = H.make_oracle(A, N, "crowd", p, seed=9)
+    g.alan_configure(alan.DEFAULT_ACTIONS); e.alan_configure(alan.DEFAULT_ACTIONS)
+    px, py = g.get(_lib.FLD_POS_X).copy(), g.get(_lib.FLD_POS_Y).copy()
+    runs = []
+    for ep in range(2):
+        g.reset(px, py, with_obs=False); e.reset(px, py, flags=0)        # the same start, the next episode
+        acts = []
+        for s in range(12):
+            g.alan_step(); e.alan_step()
+            acts.append(g.get(_lib.FLD_ALAN_ACTION).copy())
+            H._eq(acts[-1], e.get(o.FLD_ALAN_ACTION), "episode %d step %d actions" % (ep, s))
+        runs.append(np.stack(acts))
+    H.assert_state_equal(g, e, "two alan episodes")
+    assert (runs[0][0] != runs[1][0]).any() and (runs[0] != runs[1]).mean() > 0.3
+    g.close()

@@ -48,7 +48,26 @@ def test_ray_and_octagon_tables(golden_dir):
     np.testing.assert_array_equal(oct_[-1, 2:], oct_[0, :2])
 
 
-def _replay(golden_dir, name, prec):
+FLIP_MARGIN = 1e-5   # a ray may differ between fp32 and the reference's fp64 only if it is this close to flipping
+
+
+def count_bad(err, tol, margins, key, env, prec, n):
+    """Rays whose error exceeds `tol`.  In the fp64 replay the flip margin of every ray is recorded (oracle field
+    OBS_MARGIN: distance of the nearest segment's (s, t) from the edge of the accepted square [0,1]^2 of utils.py:21-31,
+    or the relative gap between the two nearest hits); in an fp32 replay every such ray must then be a flip at a
+    segment end / ray tip or between two equidistant hits -- anything else is a real error and fails."""
+    bad = err.reshape(n, 16, 4).max(axis=2) > tol
+    if margins is not None:
+        if prec == o.PREC_F64:
+            margins[key] = env.get(o.FLD_OBS_MARGIN)[0].copy()
+        elif bad.any():
+            m = margins[key]
+            assert (m[bad] < FLIP_MARGIN).all(), "%s: rays %s differ by %s with flip margins %s" % (
+                key, np.argwhere(bad).tolist(), err.reshape(n, 16, 4).max(axis=2)[bad], m[bad])
+    return int(bad.sum())
+
+
+def _replay(golden_dir, name, prec, margins=None):
     g = np.load(os.path.join(golden_dir, name))
     n = int(g["n_agents"])
     cfg = o.make_config(n_arenas=1, n_agents=n, max_obst_neighbors=16)
@@ -65,12 +84,14 @@ def _replay(golden_dir, name, prec):
     rew_fld = o.FLD_REWARD64 if prec == o.PREC_F64 else o.FLD_REWARD
     tol = 1e-11 if prec == o.PREC_F64 else 3e-5
     obs_bad = obs_tot = 0
+    if margins is not None and prec == o.PREC_F64:
+        margins.clear()
     for s in range(len(g["kind"])):
         if s in reset_at:
             k = reset_at[s]
             env.reset(g["reset_pos"][k][:, 0], g["reset_pos"][k][:, 1], flags=o.F_OBS, prec=prec)
             err = np.abs(env.get(obs_fld)[0].astype(np.float64) - g["reset_obs"][k])
-            obs_bad += int((err.reshape(n, 16, 4).max(axis=2) > tol).sum()); obs_tot += n * 16
+            obs_bad += count_bad(err, tol, margins, ("reset", k), env, prec, n); obs_tot += n * 16
         if g["kind"][s] == 1:
             env.orca_step(flags=o.F_OBS | o.F_NODONE, prec=prec)
         else:
@@ -90,7 +111,7 @@ def _replay(golden_dir, name, prec):
         np.testing.assert_array_equal(st["goal_x"][0], g["tgt"][s][:, 0])
         if s in obs_at:
             err = np.abs(env.get(obs_fld)[0].astype(np.float64) - g["obs"][obs_at[s]])
-            obs_bad += int((err.reshape(n, 16, 4).max(axis=2) > tol).sum()); obs_tot += n * 16
+            obs_bad += count_bad(err, tol, margins, ("step", s), env, prec, n); obs_tot += n * 16
     assert int(env.get(o.FLD_STEP_COUNT)[0]) == int(g["step_count_final"])
     return obs_bad, obs_tot
 
@@ -101,9 +122,19 @@ def test_env_loop_f64_matches_reference(golden_dir, name):
     assert tot > 1000 and bad == 0, (bad, tot)
 
 
+def flip_margins(golden_dir, name):
+    """{("reset", k) | ("step", s): [n, 16] flip margins} from the fp64 replay of a golden run."""
+    margins = {}
+    bad, tot = _replay(golden_dir, name, o.PREC_F64, margins)
+    assert bad == 0
+    return margins
+
+
 @pytest.mark.parametrize("name", ["env_doorway_n10.npz", "env_doorway_n6_dense.npz"])
 def test_env_loop_f32_close_to_reference(golden_dir, name):
-    bad, tot = _replay(golden_dir, name, o.PREC_F32)
+    """fp32 observation arithmetic against the reference's fp64: within 3e-5 except rays that graze a segment end
+    (counted, bounded, and each one checked to BE such a ray)."""
+    bad, tot = _replay(golden_dir, name, o.PREC_F32, flip_margins(golden_dir, name))
     assert bad <= max(2, tot // 500), (bad, tot)
 
 

@@ -13,6 +13,7 @@ for wl in C2 C5; do timeout -k 10 300 python3 $R/bench.py --workload $wl > $O/${
 timeout -k 10 300 python3 $R/bench.py --mode orca > $O/${T}_bench_C3_orca.json 2>>$O/bench.err || exit 1
 timeout -k 10 300 python3 $R/bench.py --variant free --no-cpu-baseline > $O/${T}_bench_C3_step_free.json 2>>$O/bench.err || exit 1
 timeout -k 10 300 python3 $R/bench.py --starts separated --no-cpu-baseline > $O/${T}_bench_C3_step_separated.json 2>>$O/bench.err || exit 1
+timeout -k 10 600 python3 $R/tools/cpu_baseline_table.py $O/${T}_cpu_baseline_table.json 4 > $O/${T}_cpu_baseline_table.txt 2>>$O/bench.err || exit 1
 echo bench done
 rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $O/kt.log 2>&1 || { tail $O/kt.log; exit 1; }
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${T}_kernel_stats_rocprofv3.csv
