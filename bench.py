@@ -33,7 +33,8 @@ VALU_PEAK_LANE_OPS = 256 * 128 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-ins
 BYTES_STEP_KERNEL_FULL = 60   # read pos 8 vel 8 goal 8 done 4 action 4; write pos 8 vel 8 done 4 stat 4 reward 4
 BYTES_STEP_KERNEL_ORCA = 52
 BYTES_OBS_KERNEL = 256        # the 64-float observation row
-MIN_WARM_SECONDS = 1.0        # clocks settle: the warm-up runs at least this long whatever --warmup says
+# clocks settle: the warm-up runs at least this long whatever --warmup says (CA_BENCH_MIN_WARM: diagnostic override)
+MIN_WARM_SECONDS = float(os.environ.get("CA_BENCH_MIN_WARM", "1.0"))
 
 
 def parse():

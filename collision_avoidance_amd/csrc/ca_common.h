@@ -31,10 +31,11 @@ struct StepArgs {
     float *orient_x, *orient_y;  // unit vector pos -> goal of the CURRENT state (frame of the observation)
     int *agent_done, *arrive_step, *regoal_count;
     // neighbour lists of the last step, packed: counts [A,N] u16 = agent neighbours | obstacle neighbours << 8;
-    // indices [A,K,N] / [A,S,N] as u8, or u16 when an arena has more than 256 agents / obstacle edges
+    // agent-neighbour ids [A,K,N] as u8, or u16 when an arena has more than 256 agents (workgroup > 256 lanes);
+    // obstacle-edge ids [A,S,N] as u16
     unsigned short* counts;
-    void *nb_idx, *obst_idx;
-    int nidx16, oidx16;
+    void* nb_idx;
+    unsigned short* obst_idx;
     int *step_count, *arena_done, *episode;
     unsigned long long* arena_stats;  // [A][8]
     const ObstDev* obst;   // the processed edge table(s)
@@ -74,12 +75,23 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// packed list entries
-__device__ __forceinline__ int ld_idx(const void* b, size_t k, int w16) {
-    return w16 ? (int)reinterpret_cast<const unsigned short*>(b)[k] : (int)reinterpret_cast<const unsigned char*>(b)[k];
+// packed list entries: the width of an agent-neighbour id is a compile-time property of the kernel (ids of at most
+// 256 agents fit a byte), obstacle-edge ids are always 16 bits.  (No run-time width test at the loads: a branch per
+// entry keeps the compiler from having a list's loads in flight together -- it cost the observation kernel 11 % --
+// and an unaligned 16-bit load with a mask instead of the branch faulted on gfx950.)
+#ifdef CA_VAR_NB16   // diagnostic build: 16-bit agent-neighbour ids whatever the arena size
+#define CA_NBW16(BS) true
+#else
+#define CA_NBW16(BS) ((BS) > 256)
+#endif
+template <bool W16>
+__device__ __forceinline__ int ld_idx_t(const void* b, size_t k) {
+    if constexpr (W16) return (int)reinterpret_cast<const unsigned short*>(b)[k];
+    else return (int)reinterpret_cast<const unsigned char*>(b)[k];
 }
-__device__ __forceinline__ void st_idx(void* b, size_t k, int v, int w16) {
-    if (w16) reinterpret_cast<unsigned short*>(b)[k] = (unsigned short)v;
+template <bool W16>
+__device__ __forceinline__ void st_idx_t(void* b, size_t k, int v) {
+    if constexpr (W16) reinterpret_cast<unsigned short*>(b)[k] = (unsigned short)v;
     else reinterpret_cast<unsigned char*>(b)[k] = (unsigned char)v;
 }
 

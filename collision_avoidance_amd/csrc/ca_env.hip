@@ -31,8 +31,9 @@ struct ca_env {
     int *agent_done = nullptr, *arrive_step = nullptr, *regoal_count = nullptr;
     // neighbour lists, packed (ca_common.h StepArgs): counts u16 [A,N]; indices u8 or u16 [A,K,N] / [A,S,N]
     unsigned short* counts = nullptr;
-    void *nb_idx = nullptr, *obst_idx = nullptr;
-    int nidx16 = 0, oidx16 = 0;
+    void* nb_idx = nullptr;
+    unsigned short* obst_idx = nullptr;
+    int nidx16 = 0;
     int* cvt_buf = nullptr;  // staging of the i32 image the ABI shows for the packed fields (ca_get / ca_set)
     size_t cvt_cap = 0;
     int *step_count = nullptr, *arena_done = nullptr, *episode = nullptr;
@@ -179,7 +180,7 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.goal2_x = e->goal2_x; a.goal2_y = e->goal2_y; a.reward = e->reward;
     a.orient_x = e->orient_x; a.orient_y = e->orient_y;
     a.agent_done = e->agent_done; a.arrive_step = e->arrive_step; a.regoal_count = e->regoal_count;
-    a.counts = e->counts; a.nb_idx = e->nb_idx; a.obst_idx = e->obst_idx; a.nidx16 = e->nidx16; a.oidx16 = e->oidx16;
+    a.counts = e->counts; a.nb_idx = e->nb_idx; a.obst_idx = e->obst_idx;
     a.tab_off = e->d_tab_off;
     a.step_count = e->step_count; a.arena_done = e->arena_done; a.episode = e->episode;
     a.arena_stats = e->arena_stats; a.obst = e->d_obst; a.actions = actions;
@@ -250,6 +251,17 @@ static hipError_t set_lds_attr_k(int BS, size_t lds) {
     }
 }
 
+typedef void (*obs_fn_t)(const ObsArgs);
+static obs_fn_t obs_fn(int obs_bs, bool w16) {  // workgroup size x width of the stored agent-neighbour ids
+    switch (obs_bs) {
+        case 1024: return w16 ? obs_kernel<1024, true> : obs_kernel<1024, false>;
+        case 512: return w16 ? obs_kernel<512, true> : obs_kernel<512, false>;
+        case 128: return w16 ? obs_kernel<128, true> : obs_kernel<128, false>;
+        case 64: return w16 ? obs_kernel<64, true> : obs_kernel<64, false>;
+        default: return w16 ? obs_kernel<256, true> : obs_kernel<256, false>;
+    }
+}
+
 static hipError_t launch_obs(ca_env* e) {
     if (!e->orient_valid) {  // positions or goals were edited from outside: re-derive the frame
         StepArgs a;
@@ -263,7 +275,7 @@ static hipError_t launch_obs(ca_env* e) {
     ObsArgs o;
     o.pos_x = e->pos_x; o.pos_y = e->pos_y; o.vel_x = e->vel_x; o.vel_y = e->vel_y;
     o.orient_x = e->orient_x; o.orient_y = e->orient_y; o.counts = e->counts; o.nb_idx = e->nb_idx;
-    o.obst_idx = e->obst_idx; o.nidx16 = e->nidx16; o.oidx16 = e->oidx16; o.obst = e->d_obst; o.tab_off = e->d_tab_off;
+    o.obst_idx = e->obst_idx; o.obst = e->d_obst; o.tab_off = e->d_tab_off;
     o.obs = e->obs;
     o.A = e->cfg.n_arenas; o.N = e->cfg.n_agents; o.S = e->S;
     o.K = e->K > 0 ? e->K : 1;  // nb_idx is allocated with one column when K == 0; counts are all zero
@@ -276,11 +288,7 @@ static hipError_t launch_obs(ca_env* e) {
     const dim3 grid((unsigned)((size_t)o.A * o.bpa)), block(obs_bs);
     const size_t lds = obs_lds_bytes(o.N, obs_bs);
     ProfScope ps(e, KIND_OBS);
-    if (obs_bs == 1024) hipLaunchKernelGGL(obs_kernel<1024>, grid, block, lds, e->stream, o);
-    else if (obs_bs == 512) hipLaunchKernelGGL(obs_kernel<512>, grid, block, lds, e->stream, o);
-    else if (obs_bs == 128) hipLaunchKernelGGL(obs_kernel<128>, grid, block, lds, e->stream, o);
-    else if (obs_bs == 64) hipLaunchKernelGGL(obs_kernel<64>, grid, block, lds, e->stream, o);
-    else hipLaunchKernelGGL(obs_kernel<256>, grid, block, lds, e->stream, o);
+    hipLaunchKernelGGL(obs_fn(obs_bs, e->nidx16 != 0), grid, block, lds, e->stream, o);
     return hipGetLastError();
 }
 
@@ -415,7 +423,8 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     {
         const char* v = getenv("CA_NBR_BS");  // diagnostic switch: power of two in [max(P, 64), 1024]
         const int want = v ? atoi(v) : 0;
-        const bool ok = want >= 64 && want <= 1024 && (want & (want - 1)) == 0 && want >= P;
+        const bool ok = want >= 64 && want <= 1024 && (want & (want - 1)) == 0 && want >= P &&
+                        CA_NBW16(want) == CA_NBW16(e->BS);  // the list entry width is a compile-time function of the block size
         e->BSn = ok ? want : e->BS;
         e->grid_n = (cfg->n_arenas + e->BSn / P - 1) / (e->BSn / P);
         const char* f = getenv("CA_FUSE_NBR");  // diagnostic switch: 0 = separate neighbour kernel
@@ -449,11 +458,11 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     for (auto p : f64s) if (r == hipSuccess) r = dalloc(e, p, an);
     int** i32s[] = {&e->agent_done, &e->arrive_step, &e->regoal_count};
     for (auto p : i32s) if (r == hipSuccess) r = dalloc(e, p, an);
-    e->nidx16 = cfg->n_agents > 256 ? 1 : 0;  // u8 indices address 256 agents
+    e->nidx16 = CA_NBW16(e->BS) ? 1 : 0;  // u8 indices address 256 agents (BS = max(64, pow2 >= N): the kernels' compile-time test)
     if (r == hipSuccess) r = dalloc(e, &e->counts, an);
     if (r == hipSuccess) r = dalloc(e, reinterpret_cast<unsigned char**>(&e->nb_idx),
                                     an * (size_t)(e->K > 0 ? e->K : 1) * (e->nidx16 ? 2 : 1));
-    if (r == hipSuccess) r = dalloc(e, reinterpret_cast<unsigned short**>(&e->obst_idx), an * (size_t)e->S);  // u8 or u16
+    if (r == hipSuccess) r = dalloc(e, &e->obst_idx, an * (size_t)e->S);
     if (r == hipSuccess) r = dalloc(e, &e->step_count, A);
     if (r == hipSuccess) r = dalloc(e, &e->arena_done, A);
     if (r == hipSuccess) r = dalloc(e, &e->episode, A);
@@ -474,10 +483,8 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         const int obs_bs = obs_block_threads(cfg->n_agents);
         const size_t ol = obs_lds_bytes(cfg->n_agents, obs_bs);
         if (ol > 48 * 1024) {
-            const void* f = obs_bs == 1024 ? reinterpret_cast<const void*>(&obs_kernel<1024>)
-                          : obs_bs == 512 ? reinterpret_cast<const void*>(&obs_kernel<512>)
-                                          : reinterpret_cast<const void*>(&obs_kernel<256>);
-            r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ol);
+            r = hipFuncSetAttribute(reinterpret_cast<const void*>(obs_fn(obs_bs, e->nidx16 != 0)),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ol);
         }
     }
     if (r == hipSuccess) r = hipStreamSynchronize(e->stream);  // the zero fills are done before the handle is handed out
@@ -551,13 +558,8 @@ static int build_table(ca_env* e, const float* verts_xy, const int32_t* poly_siz
     return CA_OK;
 }
 
-__global__ void clear_obst_counts_kernel(unsigned short* counts, unsigned n) {
-    const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < n) counts[q] &= 0x00FFu;
-}
-
 // installs the table(s): `all` = every table concatenated, `offs` empty (one table for all arenas) or [A + 1]
-static int install_tables(ca_env* e, std::vector<ObstDev>& all, std::vector<int>& offs, size_t largest) {
+static int install_tables(ca_env* e, std::vector<ObstDev>& all, std::vector<int>& offs) {
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (e->d_obst) HIPCHK(e, hipFree(e->d_obst));
@@ -569,14 +571,6 @@ static int install_tables(ca_env* e, std::vector<ObstDev>& all, std::vector<int>
     if (!offs.empty()) {
         HIPCHK(e, hipMalloc((void**)&e->d_tab_off, offs.size() * sizeof(int)));
         HIPCHK(e, upload(e, e->d_tab_off, offs.data(), offs.size() * sizeof(int)));
-    }
-    const int w16 = largest > 256 ? 1 : 0;  // u8 ids address 256 edges
-    if (w16 != e->oidx16) {  // the stored obstacle-neighbour ids change width: the (stale anyway) lists are emptied
-        const unsigned an = (unsigned)AN(e);
-        hipLaunchKernelGGL(clear_obst_counts_kernel, dim3((an + 255) / 256), dim3(256), 0, e->stream, e->counts, an);
-        HIPCHK(e, hipGetLastError());
-        HIPCHK(e, hipStreamSynchronize(e->stream));
-        e->oidx16 = w16;
     }
     e->h_obst.swap(all);
     e->h_tab_off.swap(offs);
@@ -590,8 +584,7 @@ int ca_set_obstacles(ca_env* e, const float* verts_xy, const int32_t* poly_sizes
     if (rc) return rc;
     if (tab.size() > 65536) return fail(e, CA_ERANGE, "ca_set_obstacles: %zu edges (at most 65536)", tab.size());
     std::vector<int> none;
-    const size_t n = tab.size();
-    return install_tables(e, tab, none, n);
+    return install_tables(e, tab, none);
 }
 
 int ca_set_obstacles_per_arena(ca_env* e, const float* verts_xy, const int32_t* poly_sizes, const int32_t* n_poly) {
@@ -599,7 +592,7 @@ int ca_set_obstacles_per_arena(ca_env* e, const float* verts_xy, const int32_t* 
     const int A = e->cfg.n_arenas;
     std::vector<ObstDev> all;
     std::vector<int> offs(1, 0);
-    size_t voff = 0, poff = 0, largest = 0;
+    size_t voff = 0, poff = 0;
     for (int a = 0; a < A; ++a) {
         if (n_poly[a] < 0 || (n_poly[a] > 0 && (!verts_xy || !poly_sizes)))
             return fail(e, CA_EINVAL, "ca_set_obstacles_per_arena: bad argument for arena %d", a);
@@ -610,12 +603,11 @@ int ca_set_obstacles_per_arena(ca_env* e, const float* verts_xy, const int32_t* 
         for (int k = 0; k < n_poly[a]; ++k) voff += (size_t)poly_sizes[poff + k];
         poff += (size_t)n_poly[a];
         if (tab.size() > 65536) return fail(e, CA_ERANGE, "ca_set_obstacles_per_arena: arena %d has %zu edges (at most 65536)", a, tab.size());
-        largest = std::max(largest, tab.size());
         all.insert(all.end(), tab.begin(), tab.end());  // next / prev stay local to the arena's table
         if (all.size() > (size_t)0x7FFFFFFF) return fail(e, CA_ERANGE, "ca_set_obstacles_per_arena: too many edges");
         offs.push_back((int)all.size());
     }
-    return install_tables(e, all, offs, largest);
+    return install_tables(e, all, offs);
 }
 
 static int get_table(ca_env* e, int arena, float* verts_xy, int32_t* next, int32_t* convex, int32_t cap, int32_t* n_out) {
@@ -766,7 +758,7 @@ __global__ void unpack_list_kernel(const void* src, int kind, int w16, int* dst,
     if (q >= n) return;
     if (kind == 0) dst[q] = (int)(reinterpret_cast<const unsigned short*>(src)[q] & 0xFFu);       // agent-neighbour count
     else if (kind == 1) dst[q] = (int)(reinterpret_cast<const unsigned short*>(src)[q] >> 8);      // obstacle-neighbour count
-    else dst[q] = ld_idx(src, q, w16);
+    else dst[q] = w16 ? ld_idx_t<true>(src, q) : ld_idx_t<false>(src, q);
 }
 __global__ void pack_list_kernel(const int* src, int kind, int w16, void* dst, size_t n) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -774,7 +766,8 @@ __global__ void pack_list_kernel(const int* src, int kind, int w16, void* dst, s
     unsigned short* c = reinterpret_cast<unsigned short*>(dst);
     if (kind == 0) c[q] = (unsigned short)((c[q] & 0xFF00u) | ((unsigned)src[q] & 0xFFu));
     else if (kind == 1) c[q] = (unsigned short)((c[q] & 0x00FFu) | (((unsigned)src[q] & 0xFFu) << 8));
-    else st_idx(dst, q, src[q], w16);
+    else if (w16) st_idx_t<true>(dst, q, src[q]);
+    else st_idx_t<false>(dst, q, src[q]);
 }
 static bool packed_field(int f) {
     return f == CA_FLD_NB_COUNT || f == CA_FLD_OBST_COUNT || f == CA_FLD_NB_IDX || f == CA_FLD_OBST_IDX;
@@ -803,7 +796,7 @@ int ca_set(ca_env* e, int32_t field, const void* src, size_t bytes, int32_t src_
         if (rc) return rc;
         HIPCHK(e, hipMemcpyAsync(e->cvt_buf, src, bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
         hipLaunchKernelGGL(pack_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->cvt_buf,
-                           packed_kind(field), field == CA_FLD_NB_IDX ? e->nidx16 : e->oidx16, fi.ptr, n);
+                           packed_kind(field), field == CA_FLD_NB_IDX ? e->nidx16 : 1, fi.ptr, n);
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipStreamSynchronize(e->stream));  // the staging buffer is free again, the caller's host array too
         return CA_OK;
@@ -826,7 +819,7 @@ int ca_get(ca_env* e, int32_t field, void* dst, size_t bytes, int32_t dst_is_dev
         const int rc = cvt_reserve(e, n);
         if (rc) return rc;
         hipLaunchKernelGGL(unpack_list_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, fi.ptr,
-                           packed_kind(field), field == CA_FLD_NB_IDX ? e->nidx16 : e->oidx16, e->cvt_buf, n);
+                           packed_kind(field), field == CA_FLD_NB_IDX ? e->nidx16 : 1, e->cvt_buf, n);
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipMemcpyAsync(dst, e->cvt_buf, bytes, dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
         HIPCHK(e, hipStreamSynchronize(e->stream));

@@ -256,10 +256,10 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
         p.counts[q] = (unsigned short)(ncnt | (ocnt << 8));
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-            if (k >= kofs) st_idx(p.nb_idx, ((size_t)a * K + (k - kofs)) * N + i, key_index(nkey[k]), p.nidx16);
+            if (k >= kofs) st_idx_t<CA_NBW16(BS)>(p.nb_idx, ((size_t)a * K + (k - kofs)) * N + i, key_index(nkey[k]));  // ids of <= 256 agents fit a byte
 #pragma unroll
         for (int k = 0; k < SMAX; ++k)
-            if (k >= sofs) st_idx(p.obst_idx, ((size_t)a * S + (k - sofs)) * N + i, key_index(okey[k]), p.oidx16);
+            if (k >= sofs) p.obst_idx[((size_t)a * S + (k - sofs)) * N + i] = (unsigned short)key_index(okey[k]);
     }
     CA_STAMP(15);
 }

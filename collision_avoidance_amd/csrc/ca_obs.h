@@ -24,8 +24,8 @@ namespace ca {
 struct ObsArgs {
     const float *pos_x, *pos_y, *vel_x, *vel_y, *orient_x, *orient_y;
     const unsigned short* counts;       // packed like StepArgs
-    const void *nb_idx, *obst_idx;
-    int nidx16, oidx16;
+    const void* nb_idx;                 // u8, or u16 when the arena has more than 256 agents (template parameter NW16)
+    const unsigned short* obst_idx;
     const ObstDev* obst;
     const int* tab_off;                 // null or [A + 1]: per-arena edge tables (see StepArgs)
     float* obs;
@@ -101,7 +101,7 @@ __device__ __forceinline__ float ray_dial(float x, float y) {
 // is < 1e-4 and the margin is 0.01 dial units (3.9e-3 rad).  Segments passing (almost) through the
 // origin, where "short way round" is ill-defined, get all 16 rays.  For an agent NEIGHBOUR the
 // window is that of the circle through its octagon's vertices (see the pre-pass).
-template <int OBS_BS>
+template <int OBS_BS, bool NW16>
 __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     constexpr int OBS_APB = OBS_BS / 16;  // agents per workgroup
     extern __shared__ float4 smem4[];
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         const int cnts = p.counts[q];
         nn = cnts & 0xFF; ns = cnts >> 8;
         c = p.orient_x[q]; s = -p.orient_y[q];  // utils.py:48-51: cos/sin of -atan2(orientation)
-        if (r < nn) s_nb[g * 16 + r] = ld_idx(p.nb_idx, ((size_t)a * K + r) * N + i, p.nidx16);
-        if (r < ns) s_ob[g * 8 + r] = ld_idx(p.obst_idx, ((size_t)a * S + r) * N + i, p.oidx16);
+        if (r < nn) s_nb[g * 16 + r] = ld_idx_t<NW16>(p.nb_idx, ((size_t)a * K + r) * N + i);
+        if (r < ns) s_ob[g * 8 + r] = (int)p.obst_idx[((size_t)a * S + r) * N + i];
     }
     s_key[g * 16 + r] = ~0ull;
     if (r == 0) { s_cnt[g] = 0; s_cnt2[g] = 0; }

@@ -100,11 +100,11 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
         int no = 0;  // obstacle lines produced so far (slots [0, no))
         {
             const float invTO = 1.0f / p.time_horizon_obst;
-            int e_next = (ocnt > 0) ? ld_idx(p.obst_idx, ((size_t)a * S + 0) * N + i, p.oidx16) : 0;
+            int e_next = (ocnt > 0) ? (int)p.obst_idx[((size_t)a * S + 0) * N + i] : 0;
             for (int s = 0; s < S; ++s) {
                 if (s < ocnt) {
                     const int e = e_next;
-                    if (s + 1 < ocnt) e_next = ld_idx(p.obst_idx, ((size_t)a * S + (s + 1)) * N + i, p.oidx16);
+                    if (s + 1 < ocnt) e_next = (int)p.obst_idx[((size_t)a * S + (s + 1)) * N + i];
                     auto covered = [&](V2 c1, V2 c2) __attribute__((always_inline)) {
                         bool c = false;
                         static_for<ST>([&](auto jc) __attribute__((always_inline)) {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
             int jn[KMAX];  // all neighbour indices in flight at once
             static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
-                jn[k] = (k < ncnt) ? ld_idx(p.nb_idx, ((size_t)a * K + k) * N + i, p.nidx16) : 0;
+                jn[k] = (k < ncnt) ? ld_idx_t<CA_NBW16(BS)>(p.nb_idx, ((size_t)a * K + k) * N + i) : 0;
             });
             static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
@@ -188,11 +188,11 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
         int nl = 0;
     {
         const float invTO = 1.0f / p.time_horizon_obst;
-        int e_next = (ocnt > 0) ? ld_idx(p.obst_idx, ((size_t)a * S + 0) * N + i, p.oidx16) : 0;
+        int e_next = (ocnt > 0) ? (int)p.obst_idx[((size_t)a * S + 0) * N + i] : 0;
         for (int s = 0; s < S; ++s) {
             if (s < ocnt) {
                 const int e = e_next;
-                if (s + 1 < ocnt) e_next = ld_idx(p.obst_idx, ((size_t)a * S + (s + 1)) * N + i, p.oidx16);
+                if (s + 1 < ocnt) e_next = (int)p.obst_idx[((size_t)a * S + (s + 1)) * N + i];
                 Line line;
                 auto covered = [&](V2 c1, V2 c2) {
                     for (int j = 0; j < nl; ++j) {
@@ -214,11 +214,11 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     {
         const float invT = 1.0f / p.time_horizon;
         const float invDt = 1.0f / p.time_step;
-        int j_next = (ncnt > 0) ? ld_idx(p.nb_idx, ((size_t)a * K + 0) * N + i, p.nidx16) : 0;
+        int j_next = (ncnt > 0) ? ld_idx_t<CA_NBW16(BS)>(p.nb_idx, ((size_t)a * K + 0) * N + i) : 0;
         for (int k = 0; k < K; ++k) {
             if (k < ncnt) {
                 const int j = lbase + j_next;
-                if (k + 1 < ncnt) j_next = ld_idx(p.nb_idx, ((size_t)a * K + (k + 1)) * N + i, p.nidx16);
+                if (k + 1 < ncnt) j_next = ld_idx_t<CA_NBW16(BS)>(p.nb_idx, ((size_t)a * K + (k + 1)) * N + i);
                 const Line line = agent_orca_line(pos, vel, mk(s_px[j], s_py[j]), mk(s_vx[j], s_vy[j]), R, invT, invDt);
                 ls.put(nl, line);
                 ++nl;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
             int jn[KMAX];  // all list entries in flight at once
             static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
-                jn[k] = (k < ncnt) ? ld_idx(p.nb_idx, ((size_t)a * K + k) * N + i, p.nidx16) : 0;
+                jn[k] = (k < ncnt) ? ld_idx_t<CA_NBW16(BS)>(p.nb_idx, ((size_t)a * K + k) * N + i) : 0;
             });
             static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;

@@ -162,8 +162,8 @@ def test_per_arena_obstacle_worlds_match_oracle(name, A, N, over, steps):
 @pytest.mark.gpu
 def test_per_arena_obstacle_ragged_and_wide_tables():
     """Worlds of different sizes in one batch: no obstacle at all, the plain border, a doorway-like world whose edges
-    processObstacles cuts, and a grid of 81 small squares (324 edges: ids no longer fit a byte, the lists switch to
-    16 bits); then a common table again through ca_set_obstacles."""
+    processObstacles cuts, and a grid of 81 small squares (324 edges: ids beyond a byte); then a common table again
+    through ca_set_obstacles."""
     from collision_avoidance_amd import _lib
     N = 10
     p = H.scenario_params("crowd", N)
@@ -184,7 +184,7 @@ def test_per_arena_obstacle_ragged_and_wide_tables():
             H.assert_state_equal(g, e, "ragged worlds step %d" % s, obs=True)
     H.assert_stats_equal(g, e, "ragged worlds")
     assert g.get(_lib.FLD_OBST_IDX).max() > 255          # ids beyond a byte were stored and read back
-    g.set_obstacles([border]); e.set_obstacles([border])  # back to one table for every arena (8-bit ids again)
+    g.set_obstacles([border]); e.set_obstacles([border])  # back to one table for every arena
     for s in range(60):
         g.orca_step(with_obs=True, stats=True); e.orca_step(flags=o.F_OBS | o.F_STATS)
     H.assert_state_equal(g, e, "common table again", obs=True)
