@@ -23,21 +23,42 @@ struct Line {
     V2 point, dir;
 };
 
-struct StepArgs {
+// Arguments of the step / reset kernels.  Kernel arguments are scalar loads that the compiler hoists to the kernel's
+// entry and then keeps in SGPRs: with every pointer and constant of the step in one by-value struct the solve kernel
+// held ~95 argument registers, spilled ~80 of them to VGPR lanes and paid ~590 v_readlane per wave (7 % of its vector
+// instructions).  So the by-value part (StepArgs) carries only what the prologue and the solve read plus what changes
+// from call to call; everything the EPILOGUE needs -- the pointers it stores through, the done / reset / re-goal
+// constants -- sits in a per-handle block in device memory (StepCold, written once by ca_create) and is loaded, as
+// scalar loads, where the epilogue begins.
+struct StepCold {
     float *pos_x, *pos_y, *vel_x, *vel_y, *pref_x, *pref_y;
     double *goal_x, *goal_y;        // targets stay fp64 like the reference's Python floats
     const double *goal2_x, *goal2_y;
     float* reward;
     float *orient_x, *orient_y;  // unit vector pos -> goal of the CURRENT state (frame of the observation)
     int *agent_done, *arrive_step, *regoal_count;
+    int *step_count, *arena_done, *episode;
+    unsigned long long* arena_stats;  // [A][8]
+    double reward_scale;
+    uint64_t seed;
+    int64_t arena_offset;
+    int max_step, done_mode;
+    float done_x_thresh;
+    float spawn_x0, spawn_x1, spawn_y0, spawn_y1, goal_x0, goal_x1, goal_y0, goal_y1;
+};
+
+struct StepArgs {
+    const float *pos_x, *pos_y, *vel_x, *vel_y, *pref_x, *pref_y;
+    const double *goal_x, *goal_y;
     // neighbour lists of the last step, packed: counts [A,N] u16 = agent neighbours | obstacle neighbours << 8;
     // agent-neighbour ids [A,K,N] as u8, or u16 when an arena has more than 256 agents (workgroup > 256 lanes);
     // obstacle-edge ids [A,S,N] as u16
     unsigned short* counts;
     void* nb_idx;
     unsigned short* obst_idx;
-    int *step_count, *arena_done, *episode;
+    const int* arena_done;
     unsigned long long* arena_stats;  // [A][8]
+    const StepCold* cold;  // device memory: the epilogue's pointers and constants (see above)
     const ObstDev* obst;   // the processed edge table(s)
     const int* tab_off;    // null: one table of n_obst edges for every arena; else [A + 1] offsets: arena a owns
                            // edges [tab_off[a], tab_off[a + 1]) and its obstacle-neighbour ids count from tab_off[a]
@@ -46,16 +67,10 @@ struct StepArgs {
     const float* reset_py;
     const int* reset_mask; // [A] reset only the arenas with a non-zero entry (reset kernels only; null = all)
     unsigned long long* dbg;  // CA_STAMPS diagnostic build only: [waves][16] phase cycle counts
-    double reward_scale;
-    uint64_t seed;
-    int64_t arena_offset;
     int n_obst, A, N, P, logP, K, S;
     int a0, a1;  // this launch covers arenas [a0, a1) (chunked launches on several streams)
     uint32_t flags;
     float time_step, neighbor_dist, time_horizon, time_horizon_obst, radius, max_speed;
-    int max_step, done_mode;
-    float done_x_thresh;
-    float spawn_x0, spawn_x1, spawn_y0, spawn_y1, goal_x0, goal_x1, goal_y0, goal_y1;
 };
 
 enum { ST_EPISODES = 0, ST_COLL = 1, ST_OBST_COLL = 2, ST_GOALS = 3, ST_OVERFLOW = 4, ST_SUMREW = 5, ST_FROZEN = 6, ST_LASTEP = 7, ST_STRIDE = 8 };
@@ -84,15 +99,18 @@ __device__ __forceinline__ void wave_lds_sync() {
 #else
 #define CA_NBW16(BS) ((BS) > 256)
 #endif
+// (the lists live in global memory; saying so keeps the accesses global_* instructions where the compiler has lost
+// track of a pointer's origin and would emit flat_* ones)
+#define CA_GLOBAL __attribute__((address_space(1)))
 template <bool W16>
 __device__ __forceinline__ int ld_idx_t(const void* b, size_t k) {
-    if constexpr (W16) return (int)reinterpret_cast<const unsigned short*>(b)[k];
-    else return (int)reinterpret_cast<const unsigned char*>(b)[k];
+    if constexpr (W16) return (int)((const CA_GLOBAL unsigned short*)b)[k];
+    else return (int)((const CA_GLOBAL unsigned char*)b)[k];
 }
 template <bool W16>
 __device__ __forceinline__ void st_idx_t(void* b, size_t k, int v) {
-    if constexpr (W16) reinterpret_cast<unsigned short*>(b)[k] = (unsigned short)v;
-    else reinterpret_cast<unsigned char*>(b)[k] = (unsigned char)v;
+    if constexpr (W16) ((CA_GLOBAL unsigned short*)b)[k] = (unsigned short)v;
+    else ((CA_GLOBAL unsigned char*)b)[k] = (unsigned char)v;
 }
 
 __device__ __forceinline__ ObstDev load_obst(const ObstDev* __restrict__ t, int i) {

@@ -55,6 +55,7 @@ struct ca_env {
     std::vector<ObstDev> h_obst;     // every table, concatenated
     std::vector<int> h_tab_off;      // empty: one table for all arenas; else [A + 1] offsets into h_obst
     int* d_tab_off = nullptr;
+    StepCold* d_cold = nullptr;      // the epilogue's arguments (ca_common.h)
     int P = 1, logP = 0, BS = 64, grid = 1, K = 0, S = 1;
     int BSn = 64, grid_n = 1;  // the neighbour kernel's own workgroup size
     bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
@@ -173,26 +174,34 @@ static void host_tables(ca_env* e) {
     e->oct[4 * k + 2] = (float)first[0]; e->oct[4 * k + 3] = (float)first[1];
 }
 
+// the per-handle block of epilogue arguments (ca_common.h StepCold); written once, at the end of ca_create
+static void fill_cold(const ca_env* e, StepCold& c) {
+    const ca_config& g = e->cfg;
+    c.pos_x = e->pos_x; c.pos_y = e->pos_y; c.vel_x = e->vel_x; c.vel_y = e->vel_y;
+    c.pref_x = e->pref_x; c.pref_y = e->pref_y; c.goal_x = e->goal_x; c.goal_y = e->goal_y;
+    c.goal2_x = e->goal2_x; c.goal2_y = e->goal2_y; c.reward = e->reward;
+    c.orient_x = e->orient_x; c.orient_y = e->orient_y;
+    c.agent_done = e->agent_done; c.arrive_step = e->arrive_step; c.regoal_count = e->regoal_count;
+    c.step_count = e->step_count; c.arena_done = e->arena_done; c.episode = e->episode;
+    c.arena_stats = e->arena_stats;
+    c.reward_scale = g.reward_scale; c.seed = g.seed; c.arena_offset = g.arena_offset;
+    c.max_step = g.max_step; c.done_mode = g.done_mode; c.done_x_thresh = g.done_x_thresh;
+    c.spawn_x0 = g.spawn_x0; c.spawn_x1 = g.spawn_x1; c.spawn_y0 = g.spawn_y0; c.spawn_y1 = g.spawn_y1;
+    c.goal_x0 = g.goal_x0; c.goal_x1 = g.goal_x1; c.goal_y0 = g.goal_y0; c.goal_y1 = g.goal_y1;
+}
+
 static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t flags) {
     const ca_config& c = e->cfg;
     a.pos_x = e->pos_x; a.pos_y = e->pos_y; a.vel_x = e->vel_x; a.vel_y = e->vel_y;
     a.pref_x = e->pref_x; a.pref_y = e->pref_y; a.goal_x = e->goal_x; a.goal_y = e->goal_y;
-    a.goal2_x = e->goal2_x; a.goal2_y = e->goal2_y; a.reward = e->reward;
-    a.orient_x = e->orient_x; a.orient_y = e->orient_y;
-    a.agent_done = e->agent_done; a.arrive_step = e->arrive_step; a.regoal_count = e->regoal_count;
     a.counts = e->counts; a.nb_idx = e->nb_idx; a.obst_idx = e->obst_idx;
-    a.tab_off = e->d_tab_off;
-    a.step_count = e->step_count; a.arena_done = e->arena_done; a.episode = e->episode;
-    a.arena_stats = e->arena_stats; a.obst = e->d_obst; a.actions = actions;
+    a.arena_done = e->arena_done; a.arena_stats = e->arena_stats; a.cold = e->d_cold;
+    a.obst = e->d_obst; a.tab_off = e->d_tab_off; a.actions = actions;
     a.reset_px = nullptr; a.reset_py = nullptr; a.reset_mask = nullptr; a.dbg = e->dbg;
-    a.reward_scale = c.reward_scale; a.seed = c.seed; a.arena_offset = c.arena_offset;
     a.n_obst = e->h_tab_off.empty() ? (int)e->h_obst.size() : 0; a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
     a.K = e->K; a.S = e->S; a.flags = flags; a.a0 = 0; a.a1 = c.n_arenas;
     a.time_step = c.time_step; a.neighbor_dist = c.neighbor_dist; a.time_horizon = c.time_horizon;
     a.time_horizon_obst = c.time_horizon_obst; a.radius = c.radius; a.max_speed = c.max_speed;
-    a.max_step = c.max_step; a.done_mode = c.done_mode; a.done_x_thresh = c.done_x_thresh;
-    a.spawn_x0 = c.spawn_x0; a.spawn_x1 = c.spawn_x1; a.spawn_y0 = c.spawn_y0; a.spawn_y1 = c.spawn_y1;
-    a.goal_x0 = c.goal_x0; a.goal_x1 = c.goal_x1; a.goal_y0 = c.goal_y0; a.goal_y1 = c.goal_y1;
 }
 
 template <int KMAX>
@@ -487,6 +496,12 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ol);
         }
     }
+    if (r == hipSuccess) r = hipMalloc((void**)&e->d_cold, sizeof(StepCold));
+    if (r == hipSuccess) {
+        StepCold hc;
+        fill_cold(e, hc);
+        r = upload(e, e->d_cold, &hc, sizeof hc);
+    }
     if (r == hipSuccess) r = hipStreamSynchronize(e->stream);  // the zero fills are done before the handle is handed out
     if (r != hipSuccess) {
         fail(nullptr, CA_EHIP, "ca_create: %s", hipGetErrorString(r));
@@ -504,7 +519,7 @@ int ca_destroy(ca_env* e) {
     void* bufs[] = {e->pos_x, e->pos_y, e->vel_x, e->vel_y, e->pref_x, e->pref_y, e->goal_x, e->goal_y,
                     e->goal2_x, e->goal2_y, e->reward, e->tmp_x, e->tmp_y, e->orient_x, e->orient_y,
                     e->agent_done, e->arrive_step,
-                    e->regoal_count, e->counts, e->nb_idx, e->obst_idx, e->cvt_buf, e->d_tab_off, e->step_count,
+                    e->regoal_count, e->counts, e->nb_idx, e->obst_idx, e->cvt_buf, e->d_tab_off, e->d_cold, e->step_count,
                     e->arena_done, e->episode, e->arena_stats, e->d_obst, e->dbg, e->dbg_obs,
                     e->alan_w, e->alan_t, e->alan_dirs, e->alan_u, e->alan_action, e->mask_buf};
     for (void* b : bufs) if (b) hipFree(b);

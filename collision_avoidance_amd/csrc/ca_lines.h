@@ -48,8 +48,10 @@ __device__ __forceinline__ Line agent_orca_line(V2 pos, V2 vel, V2 opos, V2 ovel
 // the oblique cases collapse the edge onto one of them, exactly as the contract's o2<-o1 / o1<-o2.
 // `covered(a, b)`: true when some earlier obstacle line already excludes both scaled end points.
 template <class CoveredFn>
-__device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, int e, V2 pos, V2 vel, float R,
-                                               float invTO, CoveredFn covered, Line& line) {
+__device__ __forceinline__ bool obst_orca_line4(const ObstDev* __restrict__ tab, int e, V2 pos, V2 vel, float R,
+                                                float invTO, CoveredFn covered, float& lpx, float& lpy, float& ldx, float& ldy) {
+    // (the line leaves through four scalars: as a struct written on a dozen return paths it stayed in scratch memory)
+#define CA_SET_LINE(P, D) do { const V2 _p = (P); const V2 _d = (D); lpx = _p.x; lpy = _p.y; ldx = _d.x; ldy = _d.y; } while (0)
     const ObstDev E = load_obst(tab, e);
     V2 o1p = mk(E.px, E.py), o2p = mk(E.qx, E.qy);
     V2 o1u = mk(E.ux, E.uy), o2u = mk(E.qux, E.quy);
@@ -65,21 +67,18 @@ __device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, 
     const float distSqLine = absSq(-rp1 - s * ov);
     if (s < 0.0f && distSq1 <= radiusSq) {
         if (o1c) {
-            line.point = mk(0.0f, 0.0f);
-            line.dir = normalize(mk(-rp1.y, rp1.x));
+            CA_SET_LINE(mk(0.0f, 0.0f), normalize(mk(-rp1.y, rp1.x)));
             return true;
         }
         return false;
     } else if (s > 1.0f && distSq2 <= radiusSq) {
         if (o2c && det(rp2, o2u) >= 0.0f) {
-            line.point = mk(0.0f, 0.0f);
-            line.dir = normalize(mk(-rp2.y, rp2.x));
+            CA_SET_LINE(mk(0.0f, 0.0f), normalize(mk(-rp2.y, rp2.x)));
             return true;
         }
         return false;
     } else if (s >= 0.0f && s < 1.0f && distSqLine <= radiusSq) {
-        line.point = mk(0.0f, 0.0f);
-        line.dir = -o1u;
+        CA_SET_LINE(mk(0.0f, 0.0f), -o1u);
         return true;
     }
     V2 leftLeg, rightLeg;
@@ -127,13 +126,11 @@ __device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, 
     const float tRight = dot(vel - rightCut, rightLeg);
     if ((t < 0.0f && tLeft < 0.0f) || (same && tLeft < 0.0f && tRight < 0.0f)) {
         const V2 unitW = normalize(vel - leftCut);
-        line.dir = mk(unitW.y, -unitW.x);
-        line.point = leftCut + R * invTO * unitW;
+        CA_SET_LINE(leftCut + R * invTO * unitW, mk(unitW.y, -unitW.x));
         return true;
     } else if (t > 1.0f && tRight < 0.0f) {
         const V2 unitW = normalize(vel - rightCut);
-        line.dir = mk(unitW.y, -unitW.x);
-        line.point = rightCut + R * invTO * unitW;
+        CA_SET_LINE(rightCut + R * invTO * unitW, mk(unitW.y, -unitW.x));
         return true;
     }
     const float INF = __int_as_float(0x7f800000);
@@ -141,19 +138,28 @@ __device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, 
     const float dLeft = (tLeft < 0.0f) ? INF : absSq(vel - (leftCut + tLeft * leftLeg));
     const float dRight = (tRight < 0.0f) ? INF : absSq(vel - (rightCut + tRight * rightLeg));
     if (dCut <= dLeft && dCut <= dRight) {
-        line.dir = -o1u;
-        line.point = leftCut + R * invTO * mk(-line.dir.y, line.dir.x);
+        const V2 dir = -o1u;
+        CA_SET_LINE(leftCut + R * invTO * mk(-dir.y, dir.x), dir);
         return true;
     } else if (dLeft <= dRight) {
         if (leftForeign) return false;
-        line.dir = leftLeg;
-        line.point = leftCut + R * invTO * mk(-line.dir.y, line.dir.x);
+        CA_SET_LINE(leftCut + R * invTO * mk(-leftLeg.y, leftLeg.x), leftLeg);
         return true;
     }
     if (rightForeign) return false;
-    line.dir = -rightLeg;
-    line.point = rightCut + R * invTO * mk(-line.dir.y, line.dir.x);
+    const V2 dir = -rightLeg;
+    CA_SET_LINE(rightCut + R * invTO * mk(-dir.y, dir.x), dir);
     return true;
+#undef CA_SET_LINE
 }
+template <class CoveredFn>
+__device__ __forceinline__ bool obst_orca_line(const ObstDev* __restrict__ tab, int e, V2 pos, V2 vel, float R,
+                                               float invTO, CoveredFn covered, Line& line) {
+    float px = 0.0f, py = 0.0f, dx = 1.0f, dy = 0.0f;
+    const bool ok = obst_orca_line4(tab, e, pos, vel, R, invTO, covered, px, py, dx, dy);
+    line.point = mk(px, py); line.dir = mk(dx, dy);
+    return ok;
+}
+
 
 }  // namespace ca

@@ -26,6 +26,8 @@ __host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S, int ST = 
 //         LP3 through a small per-wave LDS pool.  Needs S <= ST; ~8 KB of LDS per wave instead of
 //         16 KB; built for 4 waves per SIMD (<= 128 VGPRs), i.e. 16 waves per CU: the 4096 arenas
 //         of the C3 workload are all resident at once instead of taking 1.6 rounds at 10 per CU.
+typedef const __attribute__((address_space(4))) StepCold ColdK;  // the cold block through the constant address space
+
 template <int KMAX, int BS, int ST, bool FUSE>
 __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs p) {
     extern __shared__ float4 smem4[];
@@ -59,15 +61,17 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     CA_STAMP(0);
     // ---- load own state (coalesced SoA) ----
     V2 pos = mk(0.0f, 0.0f), vel = mk(0.0f, 0.0f), pref = mk(0.0f, 0.0f);
-    int done = 1;
+    // Long-lived per-agent values are kept OUT of registers across the solve (the register-line LP runs at the
+    // 128-VGPR limit of four waves per SIMD, and what the allocator spills goes to scratch = HBM traffic): the
+    // goal direction waits in the lane's s_misc slot, the position is re-read from the staged arena, the done flag
+    // is loaded where the done test needs it.
     // goal direction and action-rotated direction of env.py:375-381, rounded to fp32 as the reward uses them (env.py:394-399
     // on the simulator's floats); the fp64 targets are read again where the done test needs them, instead of living
     // in four registers across the solve
-    V2 pf32 = mk(1.0f, 0.0f), rl32 = mk(1.0f, 0.0f);
+    V2 pf32 = mk(1.0f, 0.0f);
     if (active) {
         pos = mk(p.pos_x[q], p.pos_y[q]);
         vel = mk(p.vel_x[q], p.vel_y[q]);
-        done = p.agent_done[q];
         if (p.actions) {  // env.py:371-383
             double pf_x, pf_y, sn, cs;
             pref_dir64(pos.x, pos.y, p.goal_x[q], p.goal_y[q], &pf_x, &pf_y);
@@ -75,17 +79,22 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
             const double rl_x = pf_x * cs - pf_y * sn;
             const double rl_y = pf_x * sn + pf_y * cs;
             pf32 = mk((float)pf_x, (float)pf_y);
-            rl32 = mk((float)rl_x, (float)rl_y);
-            pref = rl32;
+            pref = mk((float)rl_x, (float)rl_y);
         } else {
             pref = mk(p.pref_x[q], p.pref_y[q]);
         }
     }
     s_px[tid] = pos.x; s_py[tid] = pos.y; s_vx[tid] = vel.x; s_vy[tid] = vel.y;
+    reinterpret_cast<float*>(s_misc)[tid * 4 + 0] = pf32.x; reinterpret_cast<float*>(s_misc)[tid * 4 + 1] = pf32.y;
     __syncthreads();
 
     CA_STAMP(1);
     // ---- neighbour lists of this step (App. A.2), produced by nbr_kernel ----
+    // (the list pointers as scalars of their own: left inside the 16-register tuple their kernel-argument load
+    // arrives in, every use after a spill reloads the whole tuple -- 16 v_readlane for one pointer)
+    const void* nb_idx_s = p.nb_idx;
+    const unsigned short* obst_idx_s = p.obst_idx;
+    asm volatile("" : "+s"(nb_idx_s), "+s"(obst_idx_s));
     const int cnts = active ? (int)p.counts[q] : 0;
     const int ocnt = cnts >> 8, ncnt = cnts & 0xFF;
     const ObstDev* tab = p.obst + ((p.tab_off != nullptr && active) ? p.tab_off[a] : 0);  // this arena's edge table
@@ -100,11 +109,11 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
         int no = 0;  // obstacle lines produced so far (slots [0, no))
         {
             const float invTO = 1.0f / p.time_horizon_obst;
-            int e_next = (ocnt > 0) ? (int)p.obst_idx[((size_t)a * S + 0) * N + i] : 0;
+            int e_next = (ocnt > 0) ? ld_idx_t<true>(obst_idx_s, ((size_t)a * S + 0) * N + i) : 0;
             for (int s = 0; s < S; ++s) {
                 if (s < ocnt) {
                     const int e = e_next;
-                    if (s + 1 < ocnt) e_next = (int)p.obst_idx[((size_t)a * S + (s + 1)) * N + i];
+                    if (s + 1 < ocnt) e_next = ld_idx_t<true>(obst_idx_s, ((size_t)a * S + (s + 1)) * N + i);
                     auto covered = [&](V2 c1, V2 c2) __attribute__((always_inline)) {
                         bool c = false;
                         static_for<ST>([&](auto jc) __attribute__((always_inline)) {
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
             int jn[KMAX];  // all neighbour indices in flight at once
             static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
-                jn[k] = (k < ncnt) ? ld_idx_t<CA_NBW16(BS)>(p.nb_idx, ((size_t)a * K + k) * N + i) : 0;
+                jn[k] = (k < ncnt) ? ld_idx_t<CA_NBW16(BS)>(nb_idx_s, ((size_t)a * K + k) * N + i) : 0;
             });
             static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
@@ -188,11 +197,11 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
         int nl = 0;
     {
         const float invTO = 1.0f / p.time_horizon_obst;
-        int e_next = (ocnt > 0) ? (int)p.obst_idx[((size_t)a * S + 0) * N + i] : 0;
+        int e_next = (ocnt > 0) ? ld_idx_t<true>(obst_idx_s, ((size_t)a * S + 0) * N + i) : 0;
         for (int s = 0; s < S; ++s) {
             if (s < ocnt) {
                 const int e = e_next;
-                if (s + 1 < ocnt) e_next = (int)p.obst_idx[((size_t)a * S + (s + 1)) * N + i];
+                if (s + 1 < ocnt) e_next = ld_idx_t<true>(obst_idx_s, ((size_t)a * S + (s + 1)) * N + i);
                 Line line;
                 auto covered = [&](V2 c1, V2 c2) {
                     for (int j = 0; j < nl; ++j) {
@@ -214,11 +223,11 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     {
         const float invT = 1.0f / p.time_horizon;
         const float invDt = 1.0f / p.time_step;
-        int j_next = (ncnt > 0) ? ld_idx_t<CA_NBW16(BS)>(p.nb_idx, ((size_t)a * K + 0) * N + i) : 0;
+        int j_next = (ncnt > 0) ? ld_idx_t<CA_NBW16(BS)>(nb_idx_s, ((size_t)a * K + 0) * N + i) : 0;
         for (int k = 0; k < K; ++k) {
             if (k < ncnt) {
                 const int j = lbase + j_next;
-                if (k + 1 < ncnt) j_next = ld_idx_t<CA_NBW16(BS)>(p.nb_idx, ((size_t)a * K + (k + 1)) * N + i);
+                if (k + 1 < ncnt) j_next = ld_idx_t<CA_NBW16(BS)>(nb_idx_s, ((size_t)a * K + (k + 1)) * N + i);
                 const Line line = agent_orca_line(pos, vel, mk(s_px[j], s_py[j]), mk(s_vx[j], s_vy[j]), R, invT, invDt);
                 ls.put(nl, line);
                 ++nl;
@@ -235,9 +244,28 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     }
     if (active) {  // ---- integrate (App. A.1) ----
         vel = nv;
-        pos = pos + vel * p.time_step;
+        pos = mk(s_px[tid], s_py[tid]) + vel * p.time_step;  // own pre-step position: still in the staged arena
     }
     CA_STAMP(7);
+    // ---- epilogue.  Its indices are derived afresh from the lane id (behind an opaque move, so that the compiler
+    // cannot keep the prologue's copies -- 64-bit element offsets, LDS addresses -- alive across the solve, where
+    // they would be spilled to scratch); the names shadow the prologue's on purpose. ----
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const StepCold* cold_e = p.cold;
+    asm volatile("" : "+s"(cold_e));  // the loads through it stay behind this point
+    {
+    // (constant address space: uniform scalar loads; after the opaque move the compiler no longer knows where the
+    // pointer came from and would use per-lane flat loads)
+    const ColdK& c = *(ColdK*)cold_e;
+    const int tid = tid_e;
+    const int la = tid >> p.logP;
+    const int i = tid & (P - 1);
+    const int a = p.a0 + blockIdx.x * apb + la;
+    const int q = active ? a * N + i : 0;
+    const int lbase = la << p.logP;
+    const ObstDev* tab = p.obst + ((p.tab_off != nullptr && active) ? p.tab_off[a] : 0);
+    pf32 = mk(reinterpret_cast<float*>(s_misc)[tid * 4 + 0], reinterpret_cast<float*>(s_misc)[tid * 4 + 1]);
 
     __syncthreads();  // every lane is done with the pre-step arena image
     s_px[tid] = pos.x; s_py[tid] = pos.y;
@@ -304,13 +332,13 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     float rew = 0.0f;
     double gx = 0.0, gy = 0.0;
     if (active) {
-        gx = p.goal_x[q]; gy = p.goal_y[q];
+        gx = c.goal_x[q]; gy = c.goal_y[q];
         if (p.actions) {
-            const float scale = (float)p.reward_scale;
+            const float scale = (float)c.reward_scale;
             const float r_goal = vel.x * pf32.x + vel.y * pf32.y;
-            const float r_polite = vel.x * rl32.x + vel.y * rl32.y;
+            const float r_polite = vel.x * pref.x + vel.y * pref.y;  // pref still is the action-rotated direction (env.py:381)
             rew = scale * r_goal + (1.0f - scale) * r_polite;
-            p.reward[q] = rew;
+            c.reward[q] = rew;
         } else {
             double dx, dy;
             pref_dir64(pos.x, pos.y, gx, gy, &dx, &dy);
@@ -322,33 +350,34 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     // ---- step counter and done test (env.py:352-365, 404-410; ALAN:118-121, 547-566) ----
     const bool nodone = (p.flags & 8u) != 0;  // CA_F_NODONE
     bool goal_changed = false;
-    int steps = active ? p.step_count[a] : 0;
+    int done = active ? c.agent_done[q] : 1;
+    int steps = active ? c.step_count[a] : 0;
     if (!p.actions && !nodone) ++steps;
     if (active && !nodone) {
         bool hit = false;
-        if (p.done_mode == 0) {
-            hit = (done == 0) && (pos.x < p.done_x_thresh);
+        if (c.done_mode == 0) {
+            hit = (done == 0) && (pos.x < c.done_x_thresh);
         } else {
             const double dx = (double)pos.x - gx, dy = (double)pos.y - gy;
             const double lim = 2.0 * (double)p.radius;
             hit = (dx * dx + dy * dy) < lim * lim;
-            if (p.done_mode == 1) hit = hit && (done == 0);
+            if (c.done_mode == 1) hit = hit && (done == 0);
         }
         if (hit) {
-            if (p.done_mode == 2) {
-                const int rc = p.regoal_count[q];
+            if (c.done_mode == 2) {
+                const int rc = c.regoal_count[q];
                 double u0, u1;
-                rng2(p.seed, p.arena_offset + a, i, RNG_REGOAL, (uint32_t)rc, &u0, &u1);
-                gx = uniform64((double)p.goal_x0, (double)p.goal_x1, u0);
-                gy = uniform64((double)p.goal_y0, (double)p.goal_y1, u1);
-                p.regoal_count[q] = rc + 1;
+                rng2(c.seed, c.arena_offset + a, i, RNG_REGOAL, (uint32_t)rc, &u0, &u1);
+                gx = uniform64((double)c.goal_x0, (double)c.goal_x1, u0);
+                gy = uniform64((double)c.goal_y0, (double)c.goal_y1, u1);
+                c.regoal_count[q] = rc + 1;
             } else {
                 done = 1;
-                p.arrive_step[q] = steps;
-                gx = p.goal2_x[q]; gy = p.goal2_y[q];
-                p.agent_done[q] = 1;
+                c.arrive_step[q] = steps;
+                gx = c.goal2_x[q]; gy = c.goal2_y[q];
+                c.agent_done[q] = 1;
             }
-            p.goal_x[q] = gx; p.goal_y[q] = gy;
+            c.goal_x[q] = gx; c.goal_y[q] = gy;
             goal_changed = true;
             atomicAdd(&red[3], 1);
         }
@@ -360,18 +389,18 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     bool all_done = false;
     if (active) {
         all_done = !nodone && (red[0] == 0);
-        if (p.max_step > 0 && steps >= p.max_step) all_done = true;
+        if (c.max_step > 0 && steps >= c.max_step) all_done = true;
     }
     const bool do_reset = all_done && (p.flags & 4u);  // CA_F_AUTORESET
     int epi = 0;
     if (do_reset) {  // env.py:461-488 for this arena
-        epi = p.episode[a];
+        epi = c.episode[a];
         double u0, u1;
-        rng2(p.seed, p.arena_offset + a, i, RNG_RESET, (uint32_t)epi, &u0, &u1);
-        pos = mk((float)uniform64((double)p.spawn_x0, (double)p.spawn_x1, u0),
-                 (float)uniform64((double)p.spawn_y0, (double)p.spawn_y1, u1));
+        rng2(c.seed, c.arena_offset + a, i, RNG_RESET, (uint32_t)epi, &u0, &u1);
+        pos = mk((float)uniform64((double)c.spawn_x0, (double)c.spawn_x1, u0),
+                 (float)uniform64((double)c.spawn_y0, (double)c.spawn_y1, u1));
         done = 0;
-        p.agent_done[q] = 0;
+        c.agent_done[q] = 0;
         double dx, dy;
         pref_dir64(pos.x, pos.y, gx, gy, &dx, &dy);
         pref = mk((float)dx, (float)dy);
@@ -382,7 +411,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
         const int w = P < 64 ? P : 64;
         for (int off = w >> 1; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
         if (active && (i & 63) == 0)
-            atomicAdd(reinterpret_cast<double*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_SUMREW]), r);
+            atomicAdd(reinterpret_cast<double*>(&c.arena_stats[(size_t)a * ST_STRIDE + ST_SUMREW]), r);
     }
     // orientation of the observation frame (env.py:236): direction to the goal from the final state.
     // After an ORCA-only step or a reset `pref` already is that vector; otherwise derive it here, once
@@ -396,12 +425,12 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     CA_STAMP(10);
     __syncthreads();  // all lanes have read red[] and episode[]
     if (active) {
-        p.orient_x[q] = ox; p.orient_y[q] = oy;
-        p.pos_x[q] = pos.x; p.pos_y[q] = pos.y;
-        p.vel_x[q] = vel.x; p.vel_y[q] = vel.y;
-        p.pref_x[q] = pref.x; p.pref_y[q] = pref.y;
+        c.orient_x[q] = ox; c.orient_y[q] = oy;
+        c.pos_x[q] = pos.x; c.pos_y[q] = pos.y;
+        c.vel_x[q] = vel.x; c.vel_y[q] = vel.y;
+        c.pref_x[q] = pref.x; c.pref_y[q] = pref.y;
         if (i == 0) {
-            unsigned long long* st = p.arena_stats + (size_t)a * ST_STRIDE;
+            unsigned long long* st = c.arena_stats + (size_t)a * ST_STRIDE;
             if (red[1]) st[ST_COLL] += (unsigned)red[1];
             if (red[2]) st[ST_OBST_COLL] += (unsigned)red[2];
             if (red[3]) st[ST_GOALS] += (unsigned)red[3];
@@ -409,10 +438,11 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
                 st[ST_EPISODES] += 1;
                 st[ST_LASTEP] = ((unsigned long long)(unsigned)steps << 32) | (unsigned)(N - red[0]);
             }
-            p.arena_done[a] = all_done ? 1 : 0;
-            p.step_count[a] = do_reset ? 0 : steps;
-            if (do_reset) p.episode[a] = epi + 1;
+            c.arena_done[a] = all_done ? 1 : 0;
+            c.step_count[a] = do_reset ? 0 : steps;
+            if (do_reset) c.episode[a] = epi + 1;
         }
+    }
     }
     CA_STAMP(11);
 }
@@ -422,6 +452,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
 // neighbour lists of the last step stay.
 // ============================================================================================
 __global__ void reset_kernel(const StepArgs p) {
+    const ColdK& c = *(ColdK*)p.cold;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= p.A * p.N) return;
     const int a = q / p.N, i = q - a * p.N;
@@ -431,32 +462,34 @@ __global__ void reset_kernel(const StepArgs p) {
         pos = mk(p.reset_px[q], p.reset_py[q]);
     } else {
         double u0, u1;
-        rng2(p.seed, p.arena_offset + a, i, RNG_RESET, (uint32_t)p.episode[a], &u0, &u1);
-        pos = mk((float)uniform64((double)p.spawn_x0, (double)p.spawn_x1, u0),
-                 (float)uniform64((double)p.spawn_y0, (double)p.spawn_y1, u1));
+        rng2(c.seed, c.arena_offset + a, i, RNG_RESET, (uint32_t)c.episode[a], &u0, &u1);
+        pos = mk((float)uniform64((double)c.spawn_x0, (double)c.spawn_x1, u0),
+                 (float)uniform64((double)c.spawn_y0, (double)c.spawn_y1, u1));
     }
     double dx, dy;
-    pref_dir64(pos.x, pos.y, p.goal_x[q], p.goal_y[q], &dx, &dy);
-    p.pos_x[q] = pos.x; p.pos_y[q] = pos.y;
-    p.pref_x[q] = (float)dx; p.pref_y[q] = (float)dy;
-    p.orient_x[q] = (float)dx; p.orient_y[q] = (float)dy;
-    p.agent_done[q] = 0;
+    pref_dir64(pos.x, pos.y, c.goal_x[q], c.goal_y[q], &dx, &dy);
+    c.pos_x[q] = pos.x; c.pos_y[q] = pos.y;
+    c.pref_x[q] = (float)dx; c.pref_y[q] = (float)dy;
+    c.orient_x[q] = (float)dx; c.orient_y[q] = (float)dy;
+    c.agent_done[q] = 0;
 }
 // orientation from scratch (after the caller overwrote positions or goals through ca_set)
 __global__ void orient_kernel(const StepArgs p) {
+    const ColdK& c = *(ColdK*)p.cold;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= p.A * p.N) return;
     double dx, dy;
-    pref_dir64(p.pos_x[q], p.pos_y[q], p.goal_x[q], p.goal_y[q], &dx, &dy);
-    p.orient_x[q] = (float)dx; p.orient_y[q] = (float)dy;
+    pref_dir64(c.pos_x[q], c.pos_y[q], c.goal_x[q], c.goal_y[q], &dx, &dy);
+    c.orient_x[q] = (float)dx; c.orient_y[q] = (float)dy;
 }
 __global__ void reset_arena_kernel(const StepArgs p) {  // after reset_kernel: per-arena counters
+    const ColdK& c = *(ColdK*)p.cold;
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= p.A) return;
     if (p.reset_mask && p.reset_mask[a] == 0) return;
-    p.step_count[a] = 0;
-    p.arena_done[a] = 0;
-    p.episode[a] += 1;
+    c.step_count[a] = 0;
+    c.arena_done[a] = 0;
+    c.episode[a] += 1;
 }
 
 }  // namespace ca
