@@ -28,7 +28,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-VALU_PEAK_LANE_OPS = 256 * 128 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz lane-instructions/s (= 157 TFLOP/s for FMAs)
+VALU_PEAK_LANE_OPS = 256 * 128 * 2.4e9  # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz: the rate behind the 157 TFLOP/s fp32 peak,
+#                                         which only packed FMAs reach (profiles/r02_valu_issue_rates_microbench.txt)
+# what a SIMD really issues for the instruction mix of these kernels: ~4.2 cycles for most vector instructions, ~2.7 for
+# plain add / mul / and / mov, 8.3 for rcp / sqrt (same file); 4.0 is the mix average used for the issue-bound estimate
+ISSUE_CYCLES_PER_VALU = 4.0
+N_SIMDS, CLOCK_HZ = 1024, 2.4e9
 # algorithmic bytes per agent-step
 BYTES_STEP_KERNEL_FULL = 60   # read pos 8 vel 8 goal 8 done 4 action 4; write pos 8 vel 8 done 4 stat 4 reward 4
 BYTES_STEP_KERNEL_ORCA = 52
@@ -261,9 +266,14 @@ def main():
                 cnt = {k: float(kk[k]["SQ_INSTS_VALU"]) for k in kms_of}
                 lane_ops = 64.0 * sum(cnt.values())
                 tsum = sum(kms_of.values()) * 1e-3
+                bound_ms = {k: cnt[k] * ISSUE_CYCLES_PER_VALU / N_SIMDS / CLOCK_HZ * 1e3 for k in kms_of}
                 valu = {"wave_insts_per_step": cnt, "lane_ops_per_s": lane_ops / tsum,
                         "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "frac": lane_ops / tsum / VALU_PEAK_LANE_OPS,
                         "per_kernel_frac": {k: 64.0 * cnt[k] / (kms_of[k] * 1e-3) / VALU_PEAK_LANE_OPS for k in kms_of},
+                        # the bound that matters: every vector instruction of the launch issued back to back on its SIMD
+                        "issue_bound_ms": bound_ms,
+                        "frac_of_issue_bound": {k: bound_ms[k] / kms_of[k] for k in kms_of},
+                        "issue_cycles_per_instruction": ISSUE_CYCLES_PER_VALU,
                         "source": "%s (SQ_INSTS_VALU per launch, same kernel sources) over the live kernel times" % csrc}
             except Exception:
                 valu = None

@@ -62,6 +62,7 @@ struct StepArgs {
     const ObstDev* obst;   // the processed edge table(s)
     const int* tab_off;    // null: one table of n_obst edges for every arena; else [A + 1] offsets: arena a owns
                            // edges [tab_off[a], tab_off[a + 1]) and its obstacle-neighbour ids count from tab_off[a]
+    const int* order;      // null, or [blocks]: workgroup b works on the arenas of block order[b] (see balance)
     const float* actions;  // null: orca_step
     const float* reset_px; // explicit reset positions (reset kernel only)
     const float* reset_py;
@@ -74,6 +75,9 @@ struct StepArgs {
 };
 
 enum { ST_EPISODES = 0, ST_COLL = 1, ST_OBST_COLL = 2, ST_GOALS = 3, ST_OVERFLOW = 4, ST_SUMREW = 5, ST_FROZEN = 6, ST_LASTEP = 7, ST_STRIDE = 8 };
+
+// the block of arenas a workgroup works on (identity unless a balancing order is installed)
+__device__ __forceinline__ int work_block(const StepArgs& p) { return p.order ? p.order[blockIdx.x] : (int)blockIdx.x; }
 
 // CA_F_FREEZE: arenas whose arena_done flag is set are left exactly as they are
 __device__ __forceinline__ bool arena_frozen(const StepArgs& p, int a) {
@@ -125,7 +129,7 @@ __device__ __forceinline__ ObstDev load_obst(const ObstDev* __restrict__ t, int 
 }
 
 #ifdef CA_STAMPS  // diagnostic build: per-wave cycle count of each phase (never in the product library)
-#if CA_STAMPS == 2   // wall-clock variant: the 100 MHz device-wide counter (wave timelines across CUs)
+#if CA_STAMPS >= 2   // wall-clock variant: the 100 MHz device-wide counter (wave timelines across CUs)
 #define CA_STAMP_CLOCK() __builtin_amdgcn_s_memrealtime()
 #else                // per-CU shader-clock counter (phase shares inside a wave)
 #define CA_STAMP_CLOCK() __builtin_amdgcn_s_memtime()
@@ -139,8 +143,23 @@ __device__ __forceinline__ ObstDev load_obst(const ObstDev* __restrict__ t, int 
             p.dbg[((size_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6)) * 16 + (k)] = _t; \
         __builtin_amdgcn_sched_barrier(0);                                               \
     } while (0)
+#if CA_STAMPS == 3   // placement variant: slots 2 and 3 of a wave's record hold its hardware id (HW_ID, XCC_ID)
+#define CA_STAMP_HWID()                                                                                    \
+    do {                                                                                                   \
+        unsigned _hw, _xcc;                                                                                \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(_hw));                                  \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(_xcc));                                \
+        if ((threadIdx.x & 63) == 0 && p.dbg) {                                                            \
+            p.dbg[((size_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6)) * 16 + 2] = _hw;                   \
+            p.dbg[((size_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6)) * 16 + 3] = _xcc;                  \
+        }                                                                                                  \
+    } while (0)
+#endif
 #else
 #define CA_STAMP(k) do { } while (0)
+#endif
+#ifndef CA_STAMP_HWID
+#define CA_STAMP_HWID() do { } while (0)
 #endif
 
 }  // namespace ca

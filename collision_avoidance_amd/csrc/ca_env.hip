@@ -56,6 +56,7 @@ struct ca_env {
     std::vector<int> h_tab_off;      // empty: one table for all arenas; else [A + 1] offsets into h_obst
     int* d_tab_off = nullptr;
     StepCold* d_cold = nullptr;      // the epilogue's arguments (ca_common.h)
+    int* d_order = nullptr;          // [grid] block order of the solve kernel (null: identity)
     int P = 1, logP = 0, BS = 64, grid = 1, K = 0, S = 1;
     int BSn = 64, grid_n = 1;  // the neighbour kernel's own workgroup size
     bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
@@ -196,7 +197,7 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.pref_x = e->pref_x; a.pref_y = e->pref_y; a.goal_x = e->goal_x; a.goal_y = e->goal_y;
     a.counts = e->counts; a.nb_idx = e->nb_idx; a.obst_idx = e->obst_idx;
     a.arena_done = e->arena_done; a.arena_stats = e->arena_stats; a.cold = e->d_cold;
-    a.obst = e->d_obst; a.tab_off = e->d_tab_off; a.actions = actions;
+    a.obst = e->d_obst; a.tab_off = e->d_tab_off; a.actions = actions; a.order = e->d_order;
     a.reset_px = nullptr; a.reset_py = nullptr; a.reset_mask = nullptr; a.dbg = e->dbg;
     a.n_obst = e->h_tab_off.empty() ? (int)e->h_obst.size() : 0; a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
     a.K = e->K; a.S = e->S; a.flags = flags; a.a0 = 0; a.a1 = c.n_arenas;
@@ -519,7 +520,7 @@ int ca_destroy(ca_env* e) {
     void* bufs[] = {e->pos_x, e->pos_y, e->vel_x, e->vel_y, e->pref_x, e->pref_y, e->goal_x, e->goal_y,
                     e->goal2_x, e->goal2_y, e->reward, e->tmp_x, e->tmp_y, e->orient_x, e->orient_y,
                     e->agent_done, e->arrive_step,
-                    e->regoal_count, e->counts, e->nb_idx, e->obst_idx, e->cvt_buf, e->d_tab_off, e->d_cold, e->step_count,
+                    e->regoal_count, e->counts, e->nb_idx, e->obst_idx, e->cvt_buf, e->d_tab_off, e->d_cold, e->d_order, e->step_count,
                     e->arena_done, e->episode, e->arena_stats, e->d_obst, e->dbg, e->dbg_obs,
                     e->alan_w, e->alan_t, e->alan_dirs, e->alan_u, e->alan_action, e->mask_buf};
     for (void* b : bufs) if (b) hipFree(b);
@@ -1106,6 +1107,24 @@ int ca_debug_math(ca_env* e, int32_t op, const void* in, void* out, int32_t n) {
     HIPCHK(e, download(e, out, dout, out_b[op] * n));
     hipFree(di);
     hipFree(dout);
+    return CA_OK;
+}
+
+/* Diagnostic (not declared in include/ca_env.h): install a block order for the solve kernel -- workgroup b then works on
+ * the arenas of block order[b] (a permutation of 0 .. grid-1; host array) -- or remove it (NULL).  Results do not depend on it. */
+int ca_debug_set_order(ca_env* e, const int32_t* order) {
+    if (!e) return CA_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->d_order) { HIPCHK(e, hipFree(e->d_order)); e->d_order = nullptr; }
+    if (!order) return CA_OK;
+    std::vector<char> seen((size_t)e->grid, 0);
+    for (int b = 0; b < e->grid; ++b) {
+        if (order[b] < 0 || order[b] >= e->grid || seen[order[b]]) return fail(e, CA_EINVAL, "ca_debug_set_order: not a permutation");
+        seen[order[b]] = 1;
+    }
+    HIPCHK(e, hipMalloc((void**)&e->d_order, (size_t)e->grid * sizeof(int)));
+    HIPCHK(e, upload(e, e->d_order, order, (size_t)e->grid * sizeof(int)));
     return CA_OK;
 }
 

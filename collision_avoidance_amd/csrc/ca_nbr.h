@@ -64,7 +64,7 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
     const int la = tid >> p.logP;
     const int i = tid & (P - 1);
     const int apb = BS >> p.logP;
-    const int a = p.a0 + blockIdx.x * apb + la;
+    const int a = p.a0 + work_block(p) * apb + la;
     const bool active = (a < p.a1) && (i < p.N) && !arena_frozen(p, a);
     const int N = p.N, K = p.K, S = p.S;
     const int q = active ? a * N + i : 0;

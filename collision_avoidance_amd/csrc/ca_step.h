@@ -41,7 +41,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     const int la = tid >> p.logP;
     const int i = tid & (P - 1);
     const int apb = BS >> p.logP;
-    const int a = p.a0 + blockIdx.x * apb + la;
+    const int a = p.a0 + work_block(p) * apb + la;
     const bool frozen = arena_frozen(p, a);  // CA_F_FREEZE: the episode of this arena is over
     const bool active = (a < p.a1) && (i < p.N) && !frozen;
     if (frozen && i == 0) p.arena_stats[(size_t)a * ST_STRIDE + ST_FROZEN] += 1;
@@ -98,8 +98,12 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     const int cnts = active ? (int)p.counts[q] : 0;
     const int ocnt = cnts >> 8, ncnt = cnts & 0xFF;
     const ObstDev* tab = p.obst + ((p.tab_off != nullptr && active) ? p.tab_off[a] : 0);  // this arena's edge table
+#if defined(CA_STAMPS) && CA_STAMPS == 3
+    CA_STAMP_HWID();
+#else
     CA_STAMP(2);
     CA_STAMP(3);
+#endif
     const float R = p.radius;
     V2 nv = mk(0.0f, 0.0f);
     if constexpr (ST > 0) {
@@ -137,7 +141,11 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
                 }
             }
         }
+#if defined(CA_STAMPS) && CA_STAMPS == 3
+        if ((tid & 63) == 0 && p.dbg) p.dbg[((size_t)blockIdx.x * (BS / 64) + (tid >> 6)) * 16 + 4] = 0;  // LP3 rounds | lanes << 32
+#else
         CA_STAMP(4);
+#endif
         {
             const float invT = 1.0f / p.time_horizon;
             const float invDt = 1.0f / p.time_step;
@@ -169,6 +177,9 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
             const unsigned long long below = (1ull << (tid & 63)) - 1ull;
             while (true) {
                 const unsigned long long m = __ballot(need);
+#if defined(CA_STAMPS) && CA_STAMPS == 3
+                if ((tid & 63) == 0 && p.dbg) p.dbg[((size_t)blockIdx.x * (BS / 64) + (tid >> 6)) * 16 + 4] += 1 + ((unsigned long long)__popcll(m) << 32);
+#endif
                 if (!m) break;
                 const int rank = __popcll(m & below);
                 const bool mine = need && rank < POOL_SLOTS;
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     const int tid = tid_e;
     const int la = tid >> p.logP;
     const int i = tid & (P - 1);
-    const int a = p.a0 + blockIdx.x * apb + la;
+    const int a = p.a0 + work_block(p) * apb + la;
     const int q = active ? a * N + i : 0;
     const int lbase = la << p.logP;
     const ObstDev* tab = p.obst + ((p.tab_off != nullptr && active) ? p.tab_off[a] : 0);
