@@ -157,7 +157,7 @@ __device__ __forceinline__ bool lp1_reg(const float4 (&L)[ML], int no, float rad
             const float num = det(M.dir, Li.point - M.point);
             const bool par = fabsf(den) <= EPS;
             const float t = num / den;
-// (bitwise operators on purpose: with && / || the compiler builds branches around single moves -- 546 branches and
+            // (bitwise operators on purpose: with && / || the compiler builds branches around single moves -- 546 branches and
             // 4 754 scalar instructions in the K = 10 kernel against 374 and 3 407 this way)
             const bool pos = den >= 0.0f;
             const bool right = !par & pos, left = !par & !pos;
