@@ -81,6 +81,18 @@ pred = M @ wgt
 print("least squares over %d random orders: residual rms %.2f us of mean %.1f us; arena work p10/p50/p90/max = %s us" % (
     len(orders), float(np.sqrt(np.mean((pred - np.concatenate(y)) ** 2))), float(np.mean(np.concatenate(y))),
     [round(float(np.percentile(wgt, q)), 1) for q in (10, 50, 90, 100)]))
+# is what the fit leaves over a property of the SIMD (persistent over the orders) or noise?
+R = (np.concatenate(y) - pred).reshape(len(orders), G)
+cc = np.corrcoef(R)
+off = cc[~np.eye(len(orders), dtype=bool)]
+gmean = R.mean(axis=0)
+print("residual of the fit per SIMD group: correlation between two orders %.3f on average; persistent part (mean over orders) "
+      "rms %.2f us, p1/p99 %s us" % (float(off.mean()), float(np.sqrt(np.mean(gmean ** 2))),
+                                      [round(float(np.percentile(gmean, q)), 1) for q in (1, 99)]))
+nw_ = C.c_int32(); hb = np.zeros((A, 16), np.uint64)
+env._call("ca_debug_stamps", env.h, hb.ctypes.data, hb.shape[0], C.byref(nw_))
+xcc = (hb[:G, 3].astype(np.int64) & 0xF)
+print("   mean residual per XCC: %s us" % [round(float(gmean[xcc == x].mean()), 2) for x in range(8)])
 # proxies: LP3 lanes / rounds of the arena (arena of block b under the last order)
 order, fin, r2, ln = orders[-1]
 arena_lanes = np.zeros(A); arena_lanes[order] = ln
@@ -99,6 +111,35 @@ def folded(cost):
     return order
 
 
+def folded_speed(cost, offset):
+    """greedy: heaviest arena first, always into the group that would finish earliest (its offset + work so far),
+    four arenas per group"""
+    import heapq
+    s = np.argsort(-cost)
+    heap = [(float(offset[g]), g) for g in range(G)]
+    heapq.heapify(heap)
+    members = [[] for _ in range(G)]
+    for a_ in s:
+        while True:
+            t, g = heapq.heappop(heap)
+            if len(members[g]) < 4:
+                break
+        members[g].append(int(a_))
+        if len(members[g]) < 4:
+            heapq.heappush(heap, (t + float(cost[a_]), g))
+    order = np.empty(A, np.int32)
+    for g in range(G):
+        for q_, a_ in enumerate(members[g]):
+            order[q_ * G + g] = a_
+    return order
+
+
+set_order(folded_speed(wgt, gmean))
+step_and_read(2)
+res = [step_and_read(1) for _ in range(8)]
+print("greedy order on fitted work + the SIMDs' persistent offsets: kernel span %.1f us (%s); group finish p10/p50/p90/max %s" % (
+    np.mean([x[1] for x in res]), [round(x[1], 1) for x in res],
+    [round(float(np.percentile(res[-1][0], q)), 1) for q in (10, 50, 90, 100)]))
 for name, cost in (("fitted work", wgt), ("LP3 lanes", arena_lanes + 0.01 * wgt), ("LP3 rounds then lanes", arena_r2 * 100 + arena_lanes)):
     set_order(folded(cost))
     step_and_read(2)
