@@ -19,7 +19,9 @@ threads = max(1, min(32, len(os.sched_getaffinity(0))))
 cases = [("crowd", 64, scenarios.bench_params(64, 5.0, 10), 11), ("crowd", 64, scenarios.bench_params(64, 5.0, 10), 12),
          ("circle", 64, H.scenario_params("circle", 64), 3), ("doorway", 10, H.scenario_params("doorway", 10), 5),
          ("crowd", 16, scenarios.bench_params(16, 1.5, 5), 7), ("deadlock", 30, H.scenario_params("deadlock", 30), 9),
-         ("crowd", 256, scenarios.bench_params(256, 5.0, 10), 13)]
+         ("crowd", 256, scenarios.bench_params(256, 5.0, 10), 13),
+         ("blocks", 12, H.scenario_params("blocks", 12), 15),            # a world per arena
+         ("crowd_separated", 64, scenarios.bench_params(64, 5.0, 10), 17)]
 for scen, N, p, seed in cases:
     t0 = time.time()
     A_case = A if N <= 64 else max(8, A // 16)
