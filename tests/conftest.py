@@ -24,8 +24,8 @@ _GPU_ORDER = (
     "test_step_with_actions_bit_exact",
     "test_full_size",
     "test_obs_adversarial_geometry",
-    "test_gpu_reproduces_reference_golden",
-    "test_gpu_reproduces_reference_orca_episodes",
+    "test_gpu_replays_reference_env_loop_golden",
+    "test_gpu_replays_reference_orca_episode_loop",
     "test_autoreset_and_explicit_reset", "test_regoal_and_rollout_call", "test_sharding_invariance",
     "test_processed_obstacle_table_equals_oracle", "test_world_without_obstacles",
     "test_per_arena_obstacle",

@@ -115,7 +115,7 @@ def test_freeze_stops_each_arena_at_its_own_end():
 
 
 @pytest.mark.parametrize("ci", [0, 1, 2, 3])
-def test_gpu_reproduces_reference_alan_runs(golden_dir, ci):
+def test_gpu_replays_reference_alan_online_runs(golden_dir, ci):
     """The recorded reference runs, replayed on the GPU with the reference's own uniforms."""
     c = load_case(golden_dir, ci)
 
@@ -209,7 +209,7 @@ def test_alan_error_behaviour():
 
 
 @pytest.mark.parametrize("ci", [0, 1, 2, 3])
-def test_gpu_reproduces_reference_orca_episodes(golden_dir, ci):
+def test_gpu_replays_reference_orca_episode_loop(golden_dir, ci):
     """run_sim(mode=0) of the reference (recorded in tests/golden/alan_orca.npz) through ca_orca_step."""
     from tests.test_oracle_alan import load_orca_case, replay_orca_episode
     c = load_orca_case(golden_dir, ci)

@@ -281,7 +281,10 @@ def _golden_replay_gpu(golden_dir, name):
 
 
 @pytest.mark.parametrize("name", ["env_doorway_n10.npz", "env_doorway_n6_dense.npz"])
-def test_gpu_reproduces_reference_golden(golden_dir, name):
+def test_gpu_replays_reference_env_loop_golden(golden_dir, name):
+    """Golden runs of the reference's own env loop (reset / step / orca_step / _get_obs / done_test around doStep) --
+    recorded with the oracle's ORCA standing in for the absent rvo2 module (tests/golden/make_golden.py), so this pins the
+    Python loops and the laser observation, not the ORCA solver itself."""
     bad, tot = _golden_replay_gpu(golden_dir, name)
     assert bad <= max(2, tot // 500), (bad, tot)
 
