@@ -1,0 +1,16 @@
+#!/bin/bash
+# Counter passes (FETCH_SIZE | WRITE_SIZE | SQ_*) for the workloads other than the default one, so that bench.py can
+# quote measured traffic for them too.  usage: tools/measure_counters.sh <tag>   (outputs under gpurun_out/<tag>/)
+set -o pipefail
+R=$GRAFT_REPO_ROOT; T=$1; O=$R/gpurun_out/$T
+mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+run() {  # workload mode A N
+  local wl=$1 mode=$2 A=$3 N=$4 args="--workload $1 --mode $2 --steps 20 --warmup 5 --no-cpu-baseline"
+  rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU -d $O/sq --output-format csv -- python3 $R/bench.py $args > $O/sq.log 2>&1 || return 1
+  rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py $args > $O/fetch.log 2>&1 || return 1
+  rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py $args > $O/write.log 2>&1 || return 1
+  python3 $R/tools/counters.py $O/fetch $O/write $O/sq $O/${T}_counters_${wl}_${mode}.json $wl $mode $A $N > /dev/null || return 1
+  rm -rf $O/sq $O/fetch $O/write
+  echo "$wl $mode done"
+}
+run C2 step 1024 16 && run C5 step 256 512 && run C3 orca 4096 64
