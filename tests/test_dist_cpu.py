@@ -55,7 +55,9 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     offset, n_local = cad.shard(A_TOTAL, rank, world)
     px, gx, st = _run_oracle(offset, n_local)
-    per_rank, total = cad.gather_stats(st)
+    per_rank, total = cad.gather_stats(st, extra={"device": 10 + rank})     # ONE all_gather: counters, reward bits, extras
+    assert [d["device"] for d in per_rank] == [10 + r for r in range(world)]
+    assert per_rank[rank]["sum_reward"] == st["sum_reward"]                 # the fp64 sum travels as its bits
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), px=px, gx=gx, offset=offset,
              total=np.array([total[k] for k in cad.STAT_KEYS]),
              mine=np.array([per_rank[rank][k] for k in cad.STAT_KEYS]))
@@ -83,3 +85,5 @@ def test_gather_stats_single_process():
               obst_overflow=0, sum_reward=1.5)
     per_rank, total = cad.gather_stats(st)
     assert per_rank == [st] and total == st
+    per_rank, total = cad.gather_stats(st, extra={"device": 3})
+    assert per_rank[0]["device"] == 3 and total == st
