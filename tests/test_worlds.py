@@ -212,3 +212,24 @@ def test_per_arena_obstacle_trainer_evaluation_over_random_block_worlds():
     for r in range(3):
         np.testing.assert_array_equal(batch.vec.obstacle_table(arena=r)["verts"], tabs[r])
     batch.vec.close(); seq.vec.close()
+
+
+def test_separated_start_crowd_is_the_crowd_with_redrawn_overlaps():
+    """SURVEY 8d bench variant: starts at least 2 r apart by redrawing (sequence 1, 2, ...) -- agents that did not
+    overlap an earlier agent keep the plain crowd's start, goals and headings are the plain crowd's."""
+    from collision_avoidance_amd import _lib
+    assert scenarios.SCENARIO_IDS["crowd_separated"] == o.SCN_CROWD_SEPARATED == _lib.SCN_CROWD_SEPARATED == 7
+    A, N = 16, 64
+    p = scenarios.bench_params(N, 5.0, 10)
+    sep = H.make_oracle(A, N, "crowd_separated", p, seed=4)
+    plain = H.make_oracle(A, N, "crowd", p, seed=4)
+    x, y = sep.get(o.FLD_POS_X).astype(np.float64), sep.get(o.FLD_POS_Y).astype(np.float64)
+    d = np.hypot(x[:, :, None] - x[:, None, :], y[:, :, None] - y[:, None, :]) + 10 * np.eye(N)[None]
+    assert d.min() >= 1.0 - 1e-6                                           # 2 r = 1: nobody starts inside anybody
+    same = (sep.get(o.FLD_POS_X) == plain.get(o.FLD_POS_X)) & (sep.get(o.FLD_POS_Y) == plain.get(o.FLD_POS_Y))
+    assert 0.5 < same.mean() < 0.95 and same[:, 0].all()                   # agent 0 never moves; later ones sometimes
+    for f in (o.FLD_GOAL_X, o.FLD_GOAL_Y, o.FLD_VEL_X, o.FLD_VEL_Y):
+        np.testing.assert_array_equal(sep.get(f), plain.get(f))
+    px, py = plain.get(o.FLD_POS_X).astype(np.float64), plain.get(o.FLD_POS_Y).astype(np.float64)
+    dp = np.hypot(px[:, :, None] - px[:, None, :], py[:, :, None] - py[:, None, :]) + 10 * np.eye(N)[None]
+    assert dp.min() < 1.0                                                  # the plain crowd does start with overlaps
