@@ -18,7 +18,6 @@ statistics at the end.
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -60,23 +59,25 @@ def parse():
 
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks with torch.distributed.run as a CHILD
-    process (nothing in this process has touched the GPU), relay its output and exit with its code."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    process (nothing in this process has touched the GPU), relay its output as it comes (a hung rank shows what it
+    printed so far) and exit with its code.  --standalone lets the launcher's own c10d store pick a free port (no
+    pre-picked port that another process could take between the probe and the bind)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
     line = None
-    for ln in r.stdout.splitlines():
+    for ln in child.stdout:
         if ln.startswith("{") and '"metric"' in ln:
-            line = ln
-    if r.returncode != 0 or line is None:
-        sys.stdout.write(r.stdout)
-        raise SystemExit(r.returncode or 1)
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+            sys.stderr.flush()
+    rc = child.wait()
+    if rc != 0 or line is None:
+        raise SystemExit(rc or 1)
     print(line)
     raise SystemExit(0)
 
@@ -212,10 +213,10 @@ def main():
         warm_run += 50
         torch.cuda.synchronize()
     env.reset_stats()
-    # the kernel launches of every 8th step of the timed region are bracketed by HIP events on the
+    # the kernel launches of every 8th step (short runs: every (steps // 8)-th) of the timed region are bracketed by HIP events on the
     # stream they run on (recorded inside the library, which is where the launches are issued);
     # sampling keeps the event records from stretching the timed region (every launch: +5 % wall)
-    env.profile(8)
+    env.profile(max(1, min(8, args.steps // 8)))  # a short run (the driver's --steps 20) still brackets >= 8 steps
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

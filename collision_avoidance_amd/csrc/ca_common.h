@@ -62,7 +62,9 @@ struct StepArgs {
     const ObstDev* obst;   // the processed edge table(s)
     const int* tab_off;    // null: one table of n_obst edges for every arena; else [A + 1] offsets: arena a owns
                            // edges [tab_off[a], tab_off[a + 1]) and its obstacle-neighbour ids count from tab_off[a]
-    const int* order;      // null, or [blocks]: workgroup b works on the arenas of block order[b] (see balance)
+#ifdef CA_STAMPS
+    const int* order;      // diagnostic build only: null, or [blocks]: workgroup b works on the arenas of block order[b]
+#endif
     const float* actions;  // null: orca_step
     const float* reset_px; // explicit reset positions (reset kernel only)
     const float* reset_py;
@@ -76,8 +78,13 @@ struct StepArgs {
 
 enum { ST_EPISODES = 0, ST_COLL = 1, ST_OBST_COLL = 2, ST_GOALS = 3, ST_OVERFLOW = 4, ST_SUMREW = 5, ST_FROZEN = 6, ST_LASTEP = 7, ST_STRIDE = 8 };
 
-// the block of arenas a workgroup works on (identity unless a balancing order is installed)
+// the block of arenas a workgroup works on: its own index (the CA_STAMPS diagnostic build can install a block order
+// for the placement experiment of tools/diag/placement.py; the product library has no such indirection)
+#ifdef CA_STAMPS
 __device__ __forceinline__ int work_block(const StepArgs& p) { return p.order ? p.order[blockIdx.x] : (int)blockIdx.x; }
+#else
+__device__ __forceinline__ int work_block(const StepArgs&) { return (int)blockIdx.x; }
+#endif
 
 // CA_F_FREEZE: arenas whose arena_done flag is set are left exactly as they are
 __device__ __forceinline__ bool arena_frozen(const StepArgs& p, int a) {

@@ -197,7 +197,10 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.pref_x = e->pref_x; a.pref_y = e->pref_y; a.goal_x = e->goal_x; a.goal_y = e->goal_y;
     a.counts = e->counts; a.nb_idx = e->nb_idx; a.obst_idx = e->obst_idx;
     a.arena_done = e->arena_done; a.arena_stats = e->arena_stats; a.cold = e->d_cold;
-    a.obst = e->d_obst; a.tab_off = e->d_tab_off; a.actions = actions; a.order = e->d_order;
+    a.obst = e->d_obst; a.tab_off = e->d_tab_off; a.actions = actions;
+#ifdef CA_STAMPS
+    a.order = e->fuse_nbr ? e->d_order : nullptr;  // (the order is sized for the solve kernel's grid)
+#endif
     a.reset_px = nullptr; a.reset_py = nullptr; a.reset_mask = nullptr; a.dbg = e->dbg;
     a.n_obst = e->h_tab_off.empty() ? (int)e->h_obst.size() : 0; a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
     a.K = e->K; a.S = e->S; a.flags = flags; a.a0 = 0; a.a1 = c.n_arenas;
@@ -574,20 +577,42 @@ static int build_table(ca_env* e, const float* verts_xy, const int32_t* poly_siz
     return CA_OK;
 }
 
-// installs the table(s): `all` = every table concatenated, `offs` empty (one table for all arenas) or [A + 1]
+// the obstacle-neighbour lists of the last step name edges of the OLD table(s): drop them (high byte of `counts`)
+__global__ void clear_obst_counts_kernel(unsigned short* counts, size_t n) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) counts[q] &= 0x00FFu;
+}
+
+// installs the table(s): `all` = every table concatenated, `offs` empty (one table for all arenas) or [A + 1].
+// The new tables are allocated and uploaded first and swapped in only when everything succeeded: a failure leaves the
+// handle as it was.  The obstacle-neighbour lists left by the last step refer to the old tables, so their counts are
+// cleared (an observation or reset before the next step then sees no obstacle segments instead of stale edge ids).
 static int install_tables(ca_env* e, std::vector<ObstDev>& all, std::vector<int>& offs) {
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (e->d_obst) HIPCHK(e, hipFree(e->d_obst));
-    e->d_obst = nullptr;
-    if (e->d_tab_off) HIPCHK(e, hipFree(e->d_tab_off));
-    e->d_tab_off = nullptr;
-    HIPCHK(e, hipMalloc((void**)&e->d_obst, (all.size() + 1) * sizeof(ObstDev)));
-    if (!all.empty()) HIPCHK(e, upload(e, e->d_obst, all.data(), all.size() * sizeof(ObstDev)));
-    if (!offs.empty()) {
-        HIPCHK(e, hipMalloc((void**)&e->d_tab_off, offs.size() * sizeof(int)));
-        HIPCHK(e, upload(e, e->d_tab_off, offs.data(), offs.size() * sizeof(int)));
+    ObstDev* n_obst = nullptr;
+    int* n_off = nullptr;
+    hipError_t r = hipMalloc((void**)&n_obst, (all.size() + 1) * sizeof(ObstDev));
+    if (r == hipSuccess && !all.empty()) r = upload(e, n_obst, all.data(), all.size() * sizeof(ObstDev));
+    if (r == hipSuccess && !offs.empty()) {
+        r = hipMalloc((void**)&n_off, offs.size() * sizeof(int));
+        if (r == hipSuccess) r = upload(e, n_off, offs.data(), offs.size() * sizeof(int));
     }
+    if (r == hipSuccess) {
+        const size_t an = AN(e);
+        hipLaunchKernelGGL(clear_obst_counts_kernel, dim3((unsigned)((an + 255) / 256)), dim3(256), 0, e->stream, e->counts, an);
+        r = hipGetLastError();
+        if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    }
+    if (r != hipSuccess) {
+        if (n_obst) hipFree(n_obst);
+        if (n_off) hipFree(n_off);
+        return fail(e, CA_EHIP, "ca_set_obstacles: %s (the previous tables stay installed)", hipGetErrorString(r));
+    }
+    if (e->d_obst) hipFree(e->d_obst);
+    if (e->d_tab_off) hipFree(e->d_tab_off);
+    e->d_obst = n_obst;
+    e->d_tab_off = n_off;
     e->h_obst.swap(all);
     e->h_tab_off.swap(offs);
     return CA_OK;
@@ -1110,6 +1135,7 @@ int ca_debug_math(ca_env* e, int32_t op, const void* in, void* out, int32_t n) {
     return CA_OK;
 }
 
+#ifdef CA_STAMPS  // the two entry points below exist in the CA_STAMPS diagnostic build only (tools/stamps.py, tools/diag/placement.py)
 /* Diagnostic (not declared in include/ca_env.h): install a block order for the solve kernel -- workgroup b then works on
  * the arenas of block order[b] (a permutation of 0 .. grid-1; host array) -- or remove it (NULL).  Results do not depend on it. */
 int ca_debug_set_order(ca_env* e, const int32_t* order) {
@@ -1118,6 +1144,7 @@ int ca_debug_set_order(ca_env* e, const int32_t* order) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (e->d_order) { HIPCHK(e, hipFree(e->d_order)); e->d_order = nullptr; }
     if (!order) return CA_OK;
+    if (!e->fuse_nbr) return fail(e, CA_EINVAL, "ca_debug_set_order: needs the fused neighbour search (CA_FUSE_NBR / CA_NBR_BS unset)");
     std::vector<char> seen((size_t)e->grid, 0);
     for (int b = 0; b < e->grid; ++b) {
         if (order[b] < 0 || order[b] >= e->grid || seen[order[b]]) return fail(e, CA_EINVAL, "ca_debug_set_order: not a permutation");
@@ -1141,6 +1168,7 @@ int ca_debug_stamps(ca_env* e, unsigned long long* out, int32_t max_waves, int32
     HIPCHK(e, download(e, out, obs ? e->dbg_obs : e->dbg, (size_t)n * 16 * 8));
     return CA_OK;
 }
+#endif  // CA_STAMPS
 
 int ca_profile(ca_env* e, int32_t period) {
     if (!e || period < 0) return fail(e, CA_EINVAL, "ca_profile: bad argument");

@@ -1,11 +1,20 @@
 // ca_kernels.h -- HIP kernels of the batched collision-avoidance step for gfx950 (MI355X).
 //
-// Mapping: one LANE per agent, one workgroup per group of arenas (a
-// workgroup never splits an arena).  The arena's positions/velocities are staged once into LDS;
-// every agent then scans its arena from LDS (broadcast reads), keeps its K nearest neighbours in
-// registers, builds its ORCA half-planes into an LDS line table laid out [line][lane] (16 B per
-// lane, conflict-free) and solves the 2-D LP over that table.  Arenas are independent, so there
-// is no inter-workgroup traffic and no XCD affinity to exploit: the grid is simply arena-major.
+// Mapping: a workgroup never splits an arena; the arena's positions / velocities are staged once
+// in LDS and every agent scans its arena from there (broadcast reads).
+//   * step_kernel (ca_step.h): one LANE per agent.  The K nearest neighbours are kept in registers as sorted keys
+//     (ca_nbr.h); the ORCA half-planes live in REGISTER slots (4 obstacle + KMAX neighbour slots, LP2 / LP1 fully
+//     unrolled; every configuration with K <= 10 and <= 4 obstacle neighbours) or, for larger K / S, in an LDS line
+//     table laid out [line][lane]; the lanes whose LP2 is infeasible solve LP3 four lanes per agent in a per-wave LDS
+//     pool (ca_lp.h lp3_coop).
+//   * quad kernel (ca_quad.h): FOUR lanes per agent for small arenas (a chip of 1024 SIMDs is otherwise left with a
+//     few hundred waves): candidates, edges, lines and LP1 clips are dealt over the quad and merged with DPP moves;
+//     one launch can advance T ORCA-only steps with the arena resident in registers / LDS (ca_rollout).
+//   * obs_kernel (ca_obs.h): 16 lanes per agent, one lane per (source, ray) pair, ds_min_u64 merge per ray.
+// Arenas are independent, so there is no inter-workgroup traffic and no XCD affinity to exploit: the grid is arena-major.
+// Diagnostics: the CA_STAMPS build (tools/stamps.py, tools/diag/placement.py; never the product library) adds phase
+// time stamps, a block order for the solve kernel and the two ca_debug_* entry points that read / install them.
+// ca_nbr.h claims 128 VGPRs for the stand-alone neighbour kernel on purpose (four waves per SIMD, see there).
 //
 // Numerics contract: fp32, no FMA contraction (-ffp-contract=off), IEEE sqrt and division, the
 // operation order of SURVEY.md Appendix A.  The CPU oracle (oracle/) obeys the same contract, so

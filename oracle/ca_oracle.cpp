@@ -1114,6 +1114,7 @@ int orc_env_set_obstacles(void* env, const float* verts_xy, const int32_t* poly_
     Env* e = (Env*)env;
     e->obst.clear();
     e->obst_a.clear();
+    for (Arena& ar : e->arenas) for (NbList& l : ar.obstNb) l.clear();  /* the old lists name edges of the old table */
     size_t off = 0;
     for (int p = 0; p < n_poly; ++p) {
         if (add_polygon(e->obst, verts_xy + 2 * off, poly_sizes[p]) < 0) return -1;
@@ -1127,6 +1128,7 @@ int orc_env_set_obstacles(void* env, const float* verts_xy, const int32_t* poly_
 int orc_env_set_obstacles_per_arena(void* env, const float* verts_xy, const int32_t* poly_sizes, const int32_t* n_poly) {
     Env* e = (Env*)env;
     e->obst.clear();
+    for (Arena& ar : e->arenas) for (NbList& l : ar.obstNb) l.clear();  /* the old lists name edges of the old tables */
     e->obst_a.assign(e->A(), std::vector<ObstVertex>());
     size_t voff = 0, poff = 0;
     for (int a = 0; a < e->A(); ++a) {
