@@ -54,6 +54,8 @@ def parse():
                     help="SURVEY 8d: uniform starts (overlaps allowed, default) or rejection-sampled non-overlapping starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--as-rank", type=int, default=None,
+                    help="rehearsal (tests): a single process plays rank R of a larger job -- arena offset R * arenas, action seed of rank R")
     return ap.parse_args()
 
 
@@ -85,7 +87,8 @@ def launch_ranks(args):
 def cpu_baseline(workload, mode, seconds, variant="walls", starts="overlap"):
     """The CPU oracle (a C++ restatement of the same path) on a bounded sample of the same workload: arenas of the
     same scenario stepped for about `seconds`, first on one core, then on all cores of this process's share of
-    the host (arenas dealt to threads).  `value` is the multi-core rate, `cores` the threads used."""
+    the host: a pool of threads, each stepping its own block of arenas through the whole sample without a per-step
+    join (oracle/ca_oracle.cpp orc_env_rollout_mt).  `value` is the multi-core rate, `cores` the threads used."""
     import numpy as np
     from collision_avoidance_amd import scenarios
     from oracle import oracle as o
@@ -93,35 +96,35 @@ def cpu_baseline(workload, mode, seconds, variant="walls", starts="overlap"):
     w = scenarios.BENCH_CONFIGS[workload]
     N = w["n_agents"]
     try:
-        cores = max(1, min(32, len(os.sched_getaffinity(0))))
+        cores = max(1, len(os.sched_getaffinity(0)))
     except Exception:
-        cores = max(1, min(32, os.cpu_count() or 1))
+        cores = max(1, os.cpu_count() or 1)
     rng = np.random.RandomState(0)
     scn = "crowd" if starts == "overlap" else "crowd_separated"
+    flags = o.F_OBS if mode == "step" else 0
 
     def run(A, threads, budget):
         p = scenarios.bench_params(N, w["neighbor_dist"], w["max_neighbors"])
         env = H.make_oracle(A, N, scn, p, seed=0, polys=None if variant == "walls" else [])
-        acts = rng.uniform(-0.5, 0.5, (8, A, N)).astype(np.float32)
-        flags = o.F_OBS if mode == "step" else 0
-        for s in range(3):
-            env.step_mt(acts[s] if mode == "step" else None, flags=flags, n_threads=threads)
+        acts = rng.uniform(-0.5, 0.5, (8, A, N)).astype(np.float32) if mode == "step" else None
+        env.rollout_mt(2, acts, flags=flags, n_threads=threads)          # warm the caches, size the sample
         t0 = time.perf_counter()
-        steps = 0
-        while time.perf_counter() - t0 < budget:
-            for s in range(5):
-                env.step_mt(acts[(steps + s) % 8] if mode == "step" else None, flags=flags, n_threads=threads)
-            steps += 5
+        env.rollout_mt(4, acts, flags=flags, n_threads=threads)
+        per_step = max(1e-6, (time.perf_counter() - t0) / 4)
+        steps = int(max(8, min(4000, budget / per_step)))
+        t0 = time.perf_counter()
+        env.rollout_mt(steps, acts, flags=flags, n_threads=threads)
         dt = time.perf_counter() - t0
         return A * N * steps / dt, steps, dt
 
     A1 = max(1, min(64, 4096 // N))
     v1, s1, d1 = run(A1, 1, seconds * 0.4)
-    Am = max(cores, min(16 * cores, (4096 // N) * cores // 4 or cores))
+    Am = cores * max(1, min(16, 1024 // N))    # every thread owns a block of whole arenas
     vm, sm, dm = run(Am, cores, seconds * 0.6)
     return {"value": vm, "unit": "agent-steps/s", "cores": cores, "kind": "port", "single_core_value": v1,
-            "sample": "%d arenas x %d agents x %d steps on %d threads (%.1f s) and %d arenas x %d steps on one (%.1f s), "
-                      "same workload (%s mode, %s, %s starts), oracle/ca_oracle.cpp -O2"
+            "sample": "thread pool: %d arenas x %d agents x %d steps on %d threads, every thread steps its own block of arenas "
+                      "through the whole sample (%.1f s); and %d arenas x %d steps on one thread (%.1f s); same workload "
+                      "(%s mode, %s, %s starts), oracle/ca_oracle.cpp -O2"
                       % (Am, N, sm, cores, dm, A1, s1, d1, mode, variant, starts)}
 
 
@@ -185,12 +188,13 @@ def main():
     w = scenarios.BENCH_CONFIGS[args.workload]
     A, N = w["n_arenas"], w["n_agents"]
     p = scenarios.bench_params(N, w["neighbor_dist"], w["max_neighbors"])
-    arena_offset, _ = cad.weak_shard(A, rank)  # weak scaling: every GPU owns A arenas of the global range
+    job_rank = rank if args.as_rank is None else args.as_rank
+    arena_offset, _ = cad.weak_shard(A, job_rank)  # weak scaling: every GPU owns A arenas of the global range
     scn = "crowd" if args.starts == "overlap" else "crowd_separated"
     env = VecCollisionAvoidanceEnv(A, N, scenario=scn, params=p, device=local, seed=0,
                                    arena_offset=arena_offset, use_torch=True,
                                    obstacles="scenario" if args.variant == "walls" else [])
-    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    gen = torch.Generator(device="cuda").manual_seed(1234 + job_rank)
     pool = (torch.rand((16, A, N), device="cuda", generator=gen) - 0.5)  # actions in [-0.5, 0.5] rad
     full = args.mode == "step"
 

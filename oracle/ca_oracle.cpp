@@ -1434,6 +1434,32 @@ int orc_env_rollout(void* env, int32_t steps, uint32_t flags, int32_t n_threads)
     return 0;
 }
 
+/* The multi-core CPU baseline: `steps` env steps with the arenas dealt in contiguous blocks to n_threads threads, each
+ * thread stepping ITS arenas through the whole sample (arena-major: an arena's state stays in that core's cache) with no
+ * per-step hand-off or join -- arenas never interact, so nothing has to meet between steps.  actions_pool: null
+ * (ORCA-only step) or [pool, A, N] heading offsets, step s uses pool entry s % pool (the same action tensor for every
+ * arena-step that orc_env_step_mt would have been handed step by step, so the two give identical states). */
+int orc_env_rollout_mt(void* env, const float* actions_pool, int32_t pool, int32_t steps, uint32_t flags, int32_t prec,
+                       int32_t n_threads) {
+    Env* e = (Env*)env;
+    const int A = e->A();
+    const size_t an = (size_t)A * e->N();
+    if (actions_pool && pool < 1) return -1;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > A) n_threads = A;
+    auto work = [=](int t) {
+        const int a0 = (int)((int64_t)A * t / n_threads), a1 = (int)((int64_t)A * (t + 1) / n_threads);
+        for (int a = a0; a < a1; ++a)
+            for (int s = 0; s < steps; ++s)
+                arena_step(*e, a, actions_pool ? actions_pool + (size_t)(s % pool) * an : nullptr, flags, prec);
+    };
+    if (n_threads == 1) { work(0); return 0; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+    for (auto& t : th) t.join();
+    return 0;
+}
+
 int orc_env_alan_configure(void* env, const double* actions_xy, int32_t n_actions, double temp, double timewindow,
                            double time_step) {
     Env* e = (Env*)env;

@@ -82,6 +82,7 @@ def lib():
     L.orc_env_step.argtypes = [vp, vp, u32, i32]
     L.orc_env_orca_step.argtypes = [vp, u32, i32]
     L.orc_env_rollout.argtypes = [vp, i32, u32, i32]
+    L.orc_env_rollout_mt.argtypes = [vp, vp, i32, i32, u32, i32, i32]
     L.orc_env_stats.argtypes = [vp, C.POINTER(Stats)]
     L.orc_env_alan_configure.argtypes = [vp, vp, i32, C.c_double, C.c_double, C.c_double]
     L.orc_env_alan_step.argtypes = [vp, vp, u32, i32]
@@ -246,6 +247,15 @@ class OracleEnv:
 
     def rollout(self, steps, flags=0, n_threads=1):
         assert self.L.orc_env_rollout(self.h, steps, flags, n_threads) == 0
+
+    def rollout_mt(self, steps, actions_pool=None, flags=F_OBS, prec=PREC_F32, n_threads=1):
+        """The multi-core CPU baseline: every thread steps its own block of arenas through all `steps` steps (no
+        per-step join).  actions_pool: None (ORCA-only) or [pool, A, N]; step s uses entry s % pool."""
+        if actions_pool is None:
+            assert self.L.orc_env_rollout_mt(self.h, None, 0, steps, flags, prec, n_threads) == 0
+        else:
+            a = np.ascontiguousarray(np.asarray(actions_pool, np.float32).reshape(-1, self.A, self.N))
+            assert self.L.orc_env_rollout_mt(self.h, _ptr(a), a.shape[0], steps, flags, prec, n_threads) == 0
 
     def alan_configure(self, actions, temp=0.2, timewindow=2.0, time_step=1 / 60.):
         a = np.ascontiguousarray(np.asarray(actions, np.float64).reshape(-1, 2))
