@@ -72,6 +72,7 @@ struct StepArgs {
     unsigned long long* dbg;  // CA_STAMPS diagnostic build only: [waves][16] phase cycle counts
     int n_obst, A, N, P, logP, K, S;
     int a0, a1;  // this launch covers arenas [a0, a1) (chunked launches on several streams)
+    int T;       // quad kernel, ORCA-only mode: steps advanced by this launch (ca_quad.h); 1 otherwise
     uint32_t flags;
     float time_step, neighbor_dist, time_horizon, time_horizon_obst, radius, max_speed;
 };

@@ -61,6 +61,9 @@ struct ca_env {
     int BSn = 64, grid_n = 1;  // the neighbour kernel's own workgroup size
     bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
     int ST = 0, KT = 16;  // solve-kernel variant: ST > 0 = register lines with ST obstacle slots; KT = KMAX
+    bool quad = false;     // four lanes per agent (ca_quad.h): small batches / small arenas
+    int BSq = 64, grid_q = 1;
+    size_t lds_q = 0;
     size_t lds = 0;
     uint64_t steps_done = 0;  // env steps executed (agent_steps = steps_done * A * N)
     float rays[32], oct[32];
@@ -203,7 +206,7 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
 #endif
     a.reset_px = nullptr; a.reset_py = nullptr; a.reset_mask = nullptr; a.dbg = e->dbg;
     a.n_obst = e->h_tab_off.empty() ? (int)e->h_obst.size() : 0; a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
-    a.K = e->K; a.S = e->S; a.flags = flags; a.a0 = 0; a.a1 = c.n_arenas;
+    a.K = e->K; a.S = e->S; a.flags = flags; a.a0 = 0; a.a1 = c.n_arenas; a.T = 1;
     a.time_step = c.time_step; a.neighbor_dist = c.neighbor_dist; a.time_horizon = c.time_horizon;
     a.time_horizon_obst = c.time_horizon_obst; a.radius = c.radius; a.max_speed = c.max_speed;
 }
@@ -238,7 +241,31 @@ template <int KMAX, int ST>
 static hipError_t launch_step_k(ca_env* e, const StepArgs& a) {
     return e->fuse_nbr ? launch_step_kf<KMAX, ST, true>(e, a) : launch_step_kf<KMAX, ST, false>(e, a);
 }
+template <int KMAX>
+static hipError_t launch_quad_k(ca_env* e, const StepArgs& a) {
+    const dim3 grid(e->grid_q), block(e->BSq);
+    ProfScope ps(e, KIND_STEP);
+    switch (e->BSq) {  // neighbour search + lines + LP + integration + reward/done, four lanes per agent, a.T steps
+        case 64: hipLaunchKernelGGL((quad_kernel<KMAX, 64>), grid, block, e->lds_q, e->stream, a); break;
+        case 128: hipLaunchKernelGGL((quad_kernel<KMAX, 128>), grid, block, e->lds_q, e->stream, a); break;
+        case 256: hipLaunchKernelGGL((quad_kernel<KMAX, 256>), grid, block, e->lds_q, e->stream, a); break;
+        default: hipLaunchKernelGGL((quad_kernel<KMAX, 512>), grid, block, e->lds_q, e->stream, a); break;
+    }
+    return hipGetLastError();
+}
+template <int KMAX>
+static hipError_t set_quad_lds_attr(int BS, size_t lds) {
+    const void* f;
+    switch (BS) {
+        case 64: f = reinterpret_cast<const void*>(&quad_kernel<KMAX, 64>); break;
+        case 128: f = reinterpret_cast<const void*>(&quad_kernel<KMAX, 128>); break;
+        case 256: f = reinterpret_cast<const void*>(&quad_kernel<KMAX, 256>); break;
+        default: f = reinterpret_cast<const void*>(&quad_kernel<KMAX, 512>); break;
+    }
+    return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
 static hipError_t launch_step(ca_env* e, const StepArgs& a) {
+    if (e->quad) return e->KT == 5 ? launch_quad_k<5>(e, a) : launch_quad_k<10>(e, a);
     if (e->ST > 0) return e->KT == 5 ? launch_step_k<5, 4>(e, a) : launch_step_k<10, 4>(e, a);
     if (e->K <= 5) return launch_step_k<5, 0>(e, a);
     if (e->K <= 10) return launch_step_k<10, 0>(e, a);
@@ -452,6 +479,17 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->ST = (allow && e->K <= 10 && e->S <= 4) ? 4 : 0;
     }
     e->lds = step_lds_bytes(e->BS, e->K, e->S, e->ST, e->KT);
+    {   // four lanes per agent (ca_quad.h) where one lane per agent would leave the chip short of waves: fewer than two
+        // waves per SIMD (1024 SIMDs) and an arena that fits a workgroup at four lanes per agent
+        const char* v = getenv("CA_QUAD");  // 0 / 1 forces the choice (tests run the parity suite both ways)
+        const bool fits = e->ST > 0 && 4 * P <= 512;  // (a 1024-lane workgroup caps the kernel at 128 VGPRs: it spills)
+        const long lane_waves = (long)e->grid * (e->BS / 64);
+        e->quad = fits && (v ? v[0] == '1' : lane_waves < 2048);
+        e->BSq = 4 * P > 64 ? 4 * P : 64;
+        const int apbq = (e->BSq / 4) / P;
+        e->grid_q = (cfg->n_arenas + apbq - 1) / apbq;
+        e->lds_q = quad_lds_bytes(e->BSq, e->KT);
+    }
     // + the statically allocated LDS of the fused neighbour search: positions, and for >= 256 lanes the grid tables
     const size_t lds_static = (size_t)e->BS * 8 + (e->BS >= 256 ? (size_t)e->BS * 2 + 16 + 1024 + 1028 : 0) + 64;
     if (e->lds + lds_static > 160 * 1024) {
@@ -492,6 +530,8 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         else if (e->K <= 10) r = set_lds_attr_k<10, 0>(e->BS, e->lds);
         else r = set_lds_attr_k<16, 0>(e->BS, e->lds);
     }
+    if (r == hipSuccess && e->quad && e->lds_q > 48 * 1024)
+        r = e->KT == 5 ? set_quad_lds_attr<5>(e->BSq, e->lds_q) : set_quad_lds_attr<10>(e->BSq, e->lds_q);
     if (r == hipSuccess) {
         const int obs_bs = obs_block_threads(cfg->n_agents);
         const size_t ol = obs_lds_bytes(cfg->n_agents, obs_bs);
@@ -1073,6 +1113,17 @@ int ca_observe(ca_env* e) {
 int ca_rollout(ca_env* e, int32_t steps, uint32_t flags) {
     if (!e || steps < 0) return fail(e, CA_EINVAL, "ca_rollout: bad argument");
     HIPCHK(e, hipSetDevice(e->device));
+    if (e->quad && !(flags & CA_F_OBS) && steps > 0) {
+        // ONE launch: the workgroup that owns an arena keeps it in registers / LDS for all `steps` steps (ca_quad.h)
+        if (e->prof_period > 1) e->profiling = (e->steps_done % (uint64_t)e->prof_period) == 0;
+        StepArgs a;
+        fill_args(e, a, nullptr, flags);
+        a.T = steps;
+        HIPCHK(e, launch_step(e, a));
+        e->orient_valid = true;
+        e->steps_done += (uint64_t)steps;
+        return CA_OK;
+    }
     for (int s = 0; s < steps; ++s) {
         const int rc = do_step(e, nullptr, flags);
         if (rc) return rc;
@@ -1196,9 +1247,9 @@ int ca_profile_read(ca_env* e, int32_t counts[4], float mean_ms[4]) {
 
 int ca_launch_info(ca_env* e, int32_t* block, int32_t* grid, int32_t* lds_bytes, int32_t* obs_grid) {
     if (!e) return CA_EINVAL;
-    if (block) *block = e->BS;
-    if (grid) *grid = e->grid;
-    if (lds_bytes) *lds_bytes = (int32_t)e->lds;
+    if (block) *block = e->quad ? e->BSq : e->BS;
+    if (grid) *grid = e->quad ? e->grid_q : e->grid;
+    if (lds_bytes) *lds_bytes = (int32_t)(e->quad ? e->lds_q : e->lds);
     if (obs_grid) {
         const int apb = obs_block_threads(e->cfg.n_agents) / 16;
         *obs_grid = (int32_t)((size_t)e->cfg.n_arenas * ((e->cfg.n_agents + apb - 1) / apb));

@@ -25,6 +25,7 @@
 // observation).
 #pragma once
 #include "ca_step.h"
+#include "ca_quad.h"
 #include "ca_alan.h"
 #include "ca_obs.h"
 

@@ -1,0 +1,123 @@
+"""The four-lanes-per-agent solve kernel (csrc/ca_quad.h) against the oracle, bit for bit, with the variant FORCED
+on (CA_QUAD=1; the library otherwise picks it only for batches that leave the chip short of waves), and its
+T-steps-per-launch rollout against T single steps.  Reference semantics: collision_avoidence_env.py:385 (one doStep
+per step), :447-458 / :570-573 and ALAN_true.py:106-123 (the ORCA-only loops ca_rollout replaces)."""
+import os
+
+import numpy as np
+import pytest
+
+from collision_avoidance_amd import scenarios
+from oracle import oracle as o
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def forced_quad():
+    old = os.environ.get("CA_QUAD")
+    os.environ["CA_QUAD"] = "1"
+    yield
+    if old is None:
+        del os.environ["CA_QUAD"]
+    else:
+        os.environ["CA_QUAD"] = old
+
+
+def _is_quad(gpu):
+    info = gpu.launch_info()
+    P = 1
+    while P < gpu.N:
+        P *= 2
+    return info["block"] == max(64, 4 * P)
+
+
+CASES = [  # name, scenario, A, N, overrides, steps
+    ("c2like", "crowd", 37, 16, dict(neighbor_dist=1.5, max_neighbors=5), 300),
+    ("c3like", "crowd", 9, 64, dict(neighbor_dist=5.0, max_neighbors=10), 150),
+    ("n128", "crowd", 3, 128, dict(neighbor_dist=5.0, max_neighbors=10), 60),
+    ("circle8", "circle", 5, 8, {}, 400),
+    ("circle33", "circle", 3, 33, {}, 200),
+    ("tiny1", "crowd", 70, 1, dict(max_neighbors=5), 50),
+    ("tiny3", "crowd", 41, 3, dict(max_neighbors=3), 200),
+    ("congested", "congested", 4, 30, {}, 300),
+    ("incoming", "incoming", 3, 26, {}, 300),
+    ("k0", "crowd", 6, 12, dict(max_neighbors=0), 100),
+    ("k7", "crowd", 6, 40, dict(max_neighbors=7, neighbor_dist=4.0), 150),
+]
+
+
+@pytest.mark.parametrize("name,scenario,A,N,over,steps", CASES, ids=[c[0] for c in CASES])
+def test_quad_orca_rollout_bit_exact(name, scenario, A, N, over, steps):
+    p = H.scenario_params(scenario, N, **over)
+    gpu = H.make_gpu(A, N, scenario, p, seed=11)
+    assert _is_quad(gpu), gpu.launch_info()
+    orc = H.make_oracle(A, N, scenario, p, seed=11)
+    done = 0
+    for chunk in (1, 2, 7, steps):          # 1 step, then launches of several steps each
+        chunk = min(chunk, steps - done)
+        if chunk <= 0:
+            break
+        gpu.rollout(chunk, stats=True)
+        orc.rollout(chunk, flags=o.F_STATS)
+        done += chunk
+        H.assert_state_equal(gpu, orc, "%s after %d steps" % (name, done))
+    H.assert_stats_equal(gpu, orc, name)
+    gpu.close()
+
+
+@pytest.mark.parametrize("N,K", [(16, 5), (64, 10), (5, 2)])
+def test_quad_step_with_actions_obs_and_autoreset(N, K):
+    A = 12
+    p = scenarios.bench_params(N, 3.0, K)
+    p.update(max_step=40, done_mode=1)
+    gpu = H.make_gpu(A, N, "crowd", p, seed=5)
+    assert _is_quad(gpu)
+    orc = H.make_oracle(A, N, "crowd", p, seed=5)
+    rng = np.random.RandomState(5)
+    for s in range(130):   # crosses three episode ends (auto-reset inside the call)
+        act = rng.uniform(-1.0, 1.0, (A, N)).astype(np.float32)
+        gpu.step(act, stats=True, autoreset=True)
+        orc.step(act, flags=o.F_OBS | o.F_STATS | o.F_AUTORESET)
+        if s % 13 == 0 or s > 120:
+            H.assert_state_equal(gpu, orc, "step %d" % s, obs=True, reward=True)
+    H.assert_stats_equal(gpu, orc, "actions")
+    gpu.close()
+
+
+def test_quad_freeze_rollout_equals_single_steps_and_oracle():
+    """Episodes of different lengths end each where the serial loop would (ALAN:121-123), inside ONE launch."""
+    A, N = 10, 12
+    p = H.scenario_params("circle", N)
+    p.update(max_step=3000)
+    one = H.make_gpu(A, N, "circle", p, seed=2)
+    many = H.make_gpu(A, N, "circle", p, seed=2)
+    orc = H.make_oracle(A, N, "circle", p, seed=2)
+    # different arenas get different head starts so that they finish at different steps
+    px, py = one.get(0), one.get(1)
+    px[1::2] *= 1.0 + 0.01 * np.arange(px[1::2].shape[0])[:, None]
+    for e in (one, many):
+        e.set(0, px); e.set(1, py)
+    orc.set(o.FLD_POS_X, px); orc.set(o.FLD_POS_Y, py)
+    many.rollout(1200, stats=True, freeze=True)                      # one launch
+    for _ in range(1200):
+        one.orca_step(stats=True, freeze=True)                        # 1200 launches
+    orc.rollout(1200, flags=o.F_STATS | o.F_FREEZE)
+    H.assert_state_equal(many, orc, "freeze rollout vs oracle")
+    H.assert_state_equal(one, orc, "freeze single steps vs oracle")
+    H.assert_stats_equal(many, orc, "freeze")
+    from collision_avoidance_amd import _lib
+    np.testing.assert_array_equal(many.get(_lib.FLD_ARRIVE_STEP), one.get(_lib.FLD_ARRIVE_STEP))
+    assert len(set(many.get(_lib.FLD_STEP_COUNT).tolist())) > 1      # the episodes really differ in length
+    for e in (one, many):
+        e.close()
+
+
+def test_quad_is_the_default_for_small_batches_only():
+    del os.environ["CA_QUAD"]
+    small = H.make_gpu(64, 16, "crowd", scenarios.bench_params(16, 1.5, 5))
+    big = H.make_gpu(4096, 64, "crowd", scenarios.bench_params(64, 5.0, 10))
+    assert _is_quad(small) and not _is_quad(big)
+    small.close(); big.close()
+    os.environ["CA_QUAD"] = "1"
