@@ -54,6 +54,9 @@ def parse():
                     help="SURVEY 8d: uniform starts (overlaps allowed, default) or rejection-sampled non-overlapping starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--rollout-chunk", type=int, default=50,
+                    help="--mode orca: steps per ca_rollout call (the ORCA-only policy rollout of env.py:570-573 / ALAN:106-123); "
+                         "1 = one ca_orca_step call per step")
     ap.add_argument("--as-rank", type=int, default=None,
                     help="rehearsal (tests): a single process plays rank R of a larger job -- arena offset R * arenas, action seed of rank R")
     return ap.parse_args()
@@ -198,11 +201,19 @@ def main():
     pool = (torch.rand((16, A, N), device="cuda", generator=gen) - 0.5)  # actions in [-0.5, 0.5] rad
     full = args.mode == "step"
 
-    def one_step(i):  # the production call: one ca_step (neighbours -> ORCA solve -> observation)
+    chunk = 1 if full else max(1, args.rollout_chunk)
+    if args.steps % chunk or args.warmup % chunk:
+        raise SystemExit("bench.py: --steps and --warmup must be multiples of --rollout-chunk (%d)" % chunk)
+    lanes_per_agent = env.launch_info()["lanes_per_agent"]
+    steps_per_launch = chunk if lanes_per_agent == 4 else 1   # (one lane per agent: ca_rollout is a loop of launches)
+
+    def one_step(i):  # the production call: one ca_step (neighbours -> ORCA solve -> observation) ...
         if full:
             env._call("ca_step", env.h, pool[i % 16].data_ptr(), _lib.F_STATS | _lib.F_OBS)
-        else:
+        elif chunk == 1:
             env._call("ca_orca_step", env.h, _lib.F_STATS)
+        elif i % chunk == 0:   # ... or one ca_rollout per `chunk` steps of an ORCA-only policy rollout
+            env._call("ca_rollout", env.h, chunk, _lib.F_STATS)
 
     # warm-up: W steps, and on until MIN_WARM_SECONDS have passed (a 5-step warm-up leaves the clocks cold:
     # round 1's driver run read 84 us per kernel where a settled chip reads 78)
@@ -212,15 +223,15 @@ def main():
     torch.cuda.synchronize()
     warm_run = args.warmup
     while time.perf_counter() - tw < MIN_WARM_SECONDS:
-        for i in range(50):
+        for i in range(50 * chunk):
             one_step(warm_run + i)
-        warm_run += 50
+        warm_run += 50 * chunk
         torch.cuda.synchronize()
     env.reset_stats()
     # the kernel launches of every 8th step (short runs: every (steps // 8)-th) of the timed region are bracketed by HIP events on the
     # stream they run on (recorded inside the library, which is where the launches are issued);
     # sampling keeps the event records from stretching the timed region (every launch: +5 % wall)
-    env.profile(max(1, min(8, args.steps // 8)))  # a short run (the driver's --steps 20) still brackets >= 8 steps
+    env.profile(1 if steps_per_launch > 1 else max(1, min(8, args.steps // 8)))  # a short run (the driver's --steps 20) still brackets >= 8 steps
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -248,7 +259,7 @@ def main():
         value = world * agents * args.steps / dt
         kbytes_of = {"nbr_kernel": 0, "step_kernel": BYTES_STEP_KERNEL_FULL if full else BYTES_STEP_KERNEL_ORCA,
                      "obs_kernel": BYTES_OBS_KERNEL}
-        kms_of = {k: v[1] for k, v in ktimes.items() if v[0] > 0 and k in kbytes_of}
+        kms_of = {k: v[1] / (steps_per_launch if k == "step_kernel" else 1) for k, v in ktimes.items() if v[0] > 0 and k in kbytes_of}
         # dominant kernel: strictly the longest average launch (no tie-break)
         dom = max(kms_of, key=lambda k: kms_of[k])
         kms, kbytes = kms_of[dom], kbytes_of[dom]
@@ -295,6 +306,7 @@ def main():
                                     else "ORCA-only step (no observation)",
                                     "boundary walls" if args.variant == "walls" else "obstacle-free", args.starts),
                        "mode": args.mode, "variant": args.variant, "starts": args.starts,
+                       "rollout_chunk": chunk, "steps_per_launch": steps_per_launch, "lanes_per_agent": lanes_per_agent,
                        "sharding": "arenas, %d per GPU" % A},
             "world_size": world,
             "ranks": [{"rank": r, "device": d["device"], "agent_steps": d["agent_steps"]}

@@ -1257,4 +1257,10 @@ int ca_launch_info(ca_env* e, int32_t* block, int32_t* grid, int32_t* lds_bytes,
     return CA_OK;
 }
 
+int ca_solver_info(ca_env* e, int32_t* lanes_per_agent) {
+    if (!e) return CA_EINVAL;
+    if (lanes_per_agent) *lanes_per_agent = e->quad ? 4 : 1;
+    return CA_OK;
+}
+
 }  // extern "C"

@@ -195,7 +195,9 @@ int ca_orca_step(ca_env* env, uint32_t flags);
 /* Replaces _get_obs() alone (env.py:231-277): recompute the observation of the current state. */
 int ca_observe(ca_env* env);
 /* `steps` consecutive ca_orca_step calls without returning to the host (with CA_F_FREEZE: every
- * arena runs to the end of its own episode, at most `steps` steps). */
+ * arena runs to the end of its own episode, at most `steps` steps): the reference's ORCA-only loops, env.py:570-573
+ * (`while True: orca_step()`) and ALAN:106-123 (run_sim).  One kernel launch for all the steps where the handle uses
+ * the four-lanes-per-agent kernel (ca_solver_info) and no observation is asked for. */
 int ca_rollout(ca_env* env, int32_t steps, uint32_t flags);
 
 /* ALAN online learning (ALAN_true.py:569-628 online_step + the counter / goal test of run_sim,
@@ -245,6 +247,12 @@ int ca_profile_read(ca_env* env, int32_t counts[4], float mean_ms[4]);
 
 /* Launch geometry chosen for this handle (for reports): threads per block, blocks, LDS bytes. */
 int ca_launch_info(ca_env* env, int32_t* block, int32_t* grid, int32_t* lds_bytes, int32_t* obs_grid);
+/* Which solve kernel the handle uses: *lanes_per_agent = 1 (one lane per agent) or 4 (four lanes per agent: chosen
+ * at ca_create for batches that would otherwise leave the chip short of waves -- fewer than two waves per SIMD -- when
+ * n_agents <= 128, max_neighbors <= 10 and max_obst_neighbors <= 4; results are identical bit for bit).  With 4,
+ * ca_rollout(env, T, flags without CA_F_OBS) is ONE kernel launch that keeps every arena in registers / LDS for its T
+ * steps; otherwise it is T launches. */
+int ca_solver_info(ca_env* env, int32_t* lanes_per_agent);
 
 #ifdef __cplusplus
 }

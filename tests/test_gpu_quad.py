@@ -26,11 +26,7 @@ def forced_quad():
 
 
 def _is_quad(gpu):
-    info = gpu.launch_info()
-    P = 1
-    while P < gpu.N:
-        P *= 2
-    return info["block"] == max(64, 4 * P)
+    return gpu.launch_info()["lanes_per_agent"] == 4
 
 
 CASES = [  # name, scenario, A, N, overrides, steps
@@ -41,8 +37,8 @@ CASES = [  # name, scenario, A, N, overrides, steps
     ("circle33", "circle", 3, 33, {}, 200),
     ("tiny1", "crowd", 70, 1, dict(max_neighbors=5), 50),
     ("tiny3", "crowd", 41, 3, dict(max_neighbors=3), 200),
-    ("congested", "congested", 4, 30, {}, 300),
-    ("incoming", "incoming", 3, 26, {}, 300),
+    ("separated", "crowd_separated", 5, 24, dict(neighbor_dist=3.0, max_neighbors=10), 300),
+    ("free", "crowd", 5, 20, dict(neighbor_dist=2.0, max_neighbors=5), 200),
     ("k0", "crowd", 6, 12, dict(max_neighbors=0), 100),
     ("k7", "crowd", 6, 40, dict(max_neighbors=7, neighbor_dist=4.0), 150),
 ]
@@ -51,9 +47,10 @@ CASES = [  # name, scenario, A, N, overrides, steps
 @pytest.mark.parametrize("name,scenario,A,N,over,steps", CASES, ids=[c[0] for c in CASES])
 def test_quad_orca_rollout_bit_exact(name, scenario, A, N, over, steps):
     p = H.scenario_params(scenario, N, **over)
-    gpu = H.make_gpu(A, N, scenario, p, seed=11)
+    polys = [] if name == "free" else None      # "free": no obstacles at all
+    gpu = H.make_gpu(A, N, scenario, p, seed=11, polys=polys)
     assert _is_quad(gpu), gpu.launch_info()
-    orc = H.make_oracle(A, N, scenario, p, seed=11)
+    orc = H.make_oracle(A, N, scenario, p, seed=11, polys=polys)
     done = 0
     for chunk in (1, 2, 7, steps):          # 1 step, then launches of several steps each
         chunk = min(chunk, steps - done)
