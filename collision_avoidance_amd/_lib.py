@@ -9,7 +9,7 @@ import os
 from . import build as _build
 
 OBS_DIM = 64
-MAX_NEIGHBORS, MAX_OBST_NEIGHBORS, MAX_AGENTS = 16, 8, 1024
+MAX_NEIGHBORS, MAX_OBST_NEIGHBORS, MAX_AGENTS = 16, 16, 1024
 DONE_XLESS, DONE_GOAL, DONE_REGOAL = 0, 1, 2
 F_OBS, F_STATS, F_AUTORESET, F_NODONE, F_FREEZE = 1, 2, 4, 8, 16
 SCN_CROWD, SCN_CIRCLE, SCN_DOORWAY, SCN_CONGESTED, SCN_INCOMING, SCN_BLOCKS, SCN_DEADLOCK, SCN_CROWD_SEPARATED = range(8)

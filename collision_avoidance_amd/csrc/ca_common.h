@@ -6,7 +6,7 @@
 
 namespace ca {
 
-constexpr int SMAX = 8;       // CA_MAX_OBST_NEIGHBORS
+constexpr int SMAX = 16;      // CA_MAX_OBST_NEIGHBORS (LDS line table; the register-line and quad kernels hold 4)
 constexpr float EPS = 0.00001f;
 
 struct ObstDev {  // one obstacle edge (this vertex -> next vertex) with everything ORCA needs about
@@ -135,6 +135,31 @@ __device__ __forceinline__ ObstDev load_obst(const ObstDev* __restrict__ t, int 
     o.convex = d.x; o.qconvex = d.y; o.pad0 = 0; o.pad1 = 0;
     return o;
 }
+
+// Wave priority by progress (step_kernel): the four waves that share a SIMD are served oldest first, so they finish one
+// after the other and the last one runs alone -- at a lone wave's issue rate -- for the final fifth of the kernel.  A wave
+// that LOWERS its priority at each phase boundary lets the waves behind it catch up, so the four stay within a phase of
+// each other and finish together (C3: step_kernel 81.8 -> 73.7 us; profiles/r03_b_wave_priority_experiment.txt).
+// Points along step_kernel: 1 after the neighbour search, 2 after the obstacle lines, 3 after the agent lines, 4 in the
+// middle of LP2, 5 after LP2, 6 after LP3 + integration, 7 after the collision statistics.  A wave starts at priority 3
+// and drops to 2, 1, 0 at the points CA_PRIO_B1 < CA_PRIO_B2 < CA_PRIO_B3 (0 = never: no priority instructions at all).
+#ifndef CA_PRIO_B1
+#define CA_PRIO_B1 2
+#define CA_PRIO_B2 3
+#define CA_PRIO_B3 5
+#endif
+#if CA_PRIO_B1 > 0
+#define CA_PRIO_START() __builtin_amdgcn_s_setprio(3)
+#define CA_PRIO_POINT(x)                                                    \
+    do {                                                                    \
+        if ((x) == CA_PRIO_B1) __builtin_amdgcn_s_setprio(2);               \
+        if ((x) == CA_PRIO_B2) __builtin_amdgcn_s_setprio(1);               \
+        if ((x) == CA_PRIO_B3) __builtin_amdgcn_s_setprio(0);               \
+    } while (0)
+#else
+#define CA_PRIO_START() do { } while (0)
+#define CA_PRIO_POINT(x) do { } while (0)
+#endif
 
 #ifdef CA_STAMPS  // diagnostic build: per-wave cycle count of each phase (never in the product library)
 #if CA_STAMPS >= 2   // wall-clock variant: the 100 MHz device-wide counter (wave timelines across CUs)

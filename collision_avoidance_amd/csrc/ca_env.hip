@@ -211,21 +211,21 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.time_horizon_obst = c.time_horizon_obst; a.radius = c.radius; a.max_speed = c.max_speed;
 }
 
-template <int KMAX>
+template <int KMAX, int SM>
 static void launch_nbr_k(ca_env* e, const StepArgs& a) {
     const dim3 grid(e->grid_n), block(e->BSn);
     ProfScope ps(e, KIND_NBR);
     switch (e->BSn) {
-        case 64: hipLaunchKernelGGL((nbr_kernel<KMAX, 64>), grid, block, 0, e->stream, a); break;
-        case 128: hipLaunchKernelGGL((nbr_kernel<KMAX, 128>), grid, block, 0, e->stream, a); break;
-        case 256: hipLaunchKernelGGL((nbr_kernel<KMAX, 256>), grid, block, 0, e->stream, a); break;
-        case 512: hipLaunchKernelGGL((nbr_kernel<KMAX, 512>), grid, block, 0, e->stream, a); break;
-        default: hipLaunchKernelGGL((nbr_kernel<KMAX, 1024>), grid, block, 0, e->stream, a); break;
+        case 64: hipLaunchKernelGGL((nbr_kernel<KMAX, 64, SM>), grid, block, 0, e->stream, a); break;
+        case 128: hipLaunchKernelGGL((nbr_kernel<KMAX, 128, SM>), grid, block, 0, e->stream, a); break;
+        case 256: hipLaunchKernelGGL((nbr_kernel<KMAX, 256, SM>), grid, block, 0, e->stream, a); break;
+        case 512: hipLaunchKernelGGL((nbr_kernel<KMAX, 512, SM>), grid, block, 0, e->stream, a); break;
+        default: hipLaunchKernelGGL((nbr_kernel<KMAX, 1024, SM>), grid, block, 0, e->stream, a); break;
     }
 }
 template <int KMAX, int ST, bool FUSE>
 static hipError_t launch_step_kf(ca_env* e, const StepArgs& a) {
-    if (!FUSE) launch_nbr_k<KMAX>(e, a);  // neighbour search as a launch of its own (diagnostic: CA_FUSE_NBR=0)
+    if (!FUSE) launch_nbr_k<KMAX, (ST > 0 ? ST : SMAX)>(e, a);  // neighbour search as a launch of its own (diagnostic: CA_FUSE_NBR=0)
     const dim3 grid(e->grid), block(e->BS);
     ProfScope ps(e, KIND_STEP);
     switch (e->BS) {  // (neighbour search +) lines + LP + integration + reward/done
@@ -321,12 +321,13 @@ static hipError_t launch_obs(ca_env* e) {
     o.K = e->K > 0 ? e->K : 1;  // nb_idx is allocated with one column when K == 0; counts are all zero
     const int obs_bs = obs_block_threads(o.N), apb = obs_bs / 16;
     o.bpa = (o.N + apb - 1) / apb;
+    o.paircap = 16 * (e->K + e->S);
     o.a0 = 0; o.dbg = e->dbg_obs;
     o.radius = e->cfg.radius;
     memcpy(o.rays, e->rays, sizeof o.rays);
     memcpy(o.oct, e->oct, sizeof o.oct);
     const dim3 grid((unsigned)((size_t)o.A * o.bpa)), block(obs_bs);
-    const size_t lds = obs_lds_bytes(o.N, obs_bs);
+    const size_t lds = obs_lds_bytes(o.N, obs_bs, o.paircap);
     ProfScope ps(e, KIND_OBS);
     hipLaunchKernelGGL(obs_fn(obs_bs, e->nidx16 != 0), grid, block, lds, e->stream, o);
     return hipGetLastError();
@@ -521,7 +522,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     if (r == hipSuccess) r = dalloc(e, &e->obs, an * CA_OBS_DIM);
     if (r == hipSuccess) r = dalloc(e, &e->d_obst, (size_t)1);
 #ifdef CA_STAMPS
-    if (r == hipSuccess) r = dalloc(e, &e->dbg, (size_t)std::max(e->grid * (e->BS / 64), e->grid_n * (e->BSn / 64)) * 16);
+    if (r == hipSuccess) r = dalloc(e, &e->dbg, (size_t)std::max(std::max(e->grid * (e->BS / 64), e->grid_n * (e->BSn / 64)), e->grid_q * (e->BSq / 64)) * 16);
     if (r == hipSuccess) r = dalloc(e, &e->dbg_obs, (size_t)cfg->n_arenas * ((cfg->n_agents + 15) / 16 + 16) * 4 * 16);
 #endif
     if (r == hipSuccess && e->lds > 48 * 1024) {
@@ -534,7 +535,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         r = e->KT == 5 ? set_quad_lds_attr<5>(e->BSq, e->lds_q) : set_quad_lds_attr<10>(e->BSq, e->lds_q);
     if (r == hipSuccess) {
         const int obs_bs = obs_block_threads(cfg->n_agents);
-        const size_t ol = obs_lds_bytes(cfg->n_agents, obs_bs);
+        const size_t ol = obs_lds_bytes(cfg->n_agents, obs_bs, 16 * (e->K + e->S));
         if (ol > 48 * 1024) {
             r = hipFuncSetAttribute(reinterpret_cast<const void*>(obs_fn(obs_bs, e->nidx16 != 0)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ol);
@@ -1212,7 +1213,7 @@ int ca_debug_stamps(ca_env* e, unsigned long long* out, int32_t max_waves, int32
     if (!e || !e->dbg) return fail(e, CA_EINVAL, "ca_debug_stamps: not a CA_STAMPS build");
     const bool obs = max_waves < 0;  // negative: the observation kernel's stamps
     if (obs) max_waves = -max_waves;
-    const int nw = obs ? e->cfg.n_arenas * ((e->cfg.n_agents + 15) / 16) * 4 : e->grid * (e->BS / 64);
+    const int nw = obs ? e->cfg.n_arenas * ((e->cfg.n_agents + 15) / 16) * 4 : (e->quad ? e->grid_q * (e->BSq / 64) : e->grid * (e->BS / 64));
     if (n_waves) *n_waves = nw;
     const int n = nw < max_waves ? nw : max_waves;
     HIPCHK(e, hipSetDevice(e->device));

@@ -185,6 +185,7 @@ __device__ __forceinline__ int lp2_reg(const float4 (&L)[ML], int no, int ncnt, 
     static_for<ML>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
         const bool valid = (i < ST) ? (i < no) : (i - ST < ncnt);
+        if constexpr (i == ST + (ML - ST) / 2) CA_PRIO_POINT(4);
         if (alive && valid) {
             const Line Li = unpack_line(L[i]);
             if (det(Li.dir, Li.point - result) > 0.0f) {

@@ -49,7 +49,8 @@ __device__ __forceinline__ void sorted_insert(double (&key)[MAXN], double x) {
 // 8 B per lane): it runs at full occupancy and is issue-bound, whereas the solve kernel is tied to
 // its 16 B x (K+S) line table per lane.
 // ============================================================================================
-template <int KMAX, int BS>
+// SM: capacity of the register list of obstacle neighbours (S <= SM): 4 for the register-line solve, SMAX for the LDS table
+template <int KMAX, int BS, int SM>
 __device__ __forceinline__ void nbr_body(const StepArgs& p) {
 #ifndef CA_NBR_NO_VGPR_PAD
     // Claim 128 VGPRs (the kernel needs 56): at most 4 waves then fit on a SIMD, so a launch that brings one
@@ -77,12 +78,12 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
 
     const float INF = __int_as_float(0x7f800000);
     // ---- obstacle neighbours (App. A.2): brute force over the edge table ----
-    const int sofs = SMAX - S;  // the S-entry list is right-aligned in the register array
+    const int sofs = SM - S;  // the S-entry list is right-aligned in the register array
     const double KEY_EMPTY = __longlong_as_double(0x7F800000FFFFFFFFll);  // (+inf, -1)
     const double KEY_DUMMY = __longlong_as_double((long long)0xFFF0000000000000ull);  // -inf: never moves
-    double okey[SMAX];
+    double okey[SM];
 #pragma unroll
-    for (int k = 0; k < SMAX; ++k) okey[k] = (k < sofs) ? KEY_DUMMY : KEY_EMPTY;
+    for (int k = 0; k < SM; ++k) okey[k] = (k < sofs) ? KEY_DUMMY : KEY_EMPTY;
     int oin = 0;
     {
         const float rangeSq = sqr(p.time_horizon_obst * p.max_speed + p.radius);
@@ -94,7 +95,7 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
                 const float dsq = distSqPointSegment(a1, a2, pos);
                 if (dsq < rangeSq) {
                     ++oin;
-                    sorted_insert<SMAX>(okey, make_key(dsq, e));
+                    sorted_insert<SM>(okey, make_key(dsq, e));
                 }
             }
         };
@@ -258,15 +259,15 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
         for (int k = 0; k < KMAX; ++k)
             if (k >= kofs) st_idx_t<CA_NBW16(BS)>(p.nb_idx, ((size_t)a * K + (k - kofs)) * N + i, key_index(nkey[k]));  // ids of <= 256 agents fit a byte
 #pragma unroll
-        for (int k = 0; k < SMAX; ++k)
+        for (int k = 0; k < SM; ++k)
             if (k >= sofs) p.obst_idx[((size_t)a * S + (k - sofs)) * N + i] = (unsigned short)key_index(okey[k]);
     }
     CA_STAMP(15);
 }
 
-template <int KMAX, int BS>
+template <int KMAX, int BS, int SM>
 __global__ __launch_bounds__(BS) void nbr_kernel(const StepArgs p) {
-    nbr_body<KMAX, BS>(p);
+    nbr_body<KMAX, BS, SM>(p);
 }
 
 }  // namespace ca

@@ -30,6 +30,7 @@ struct ObsArgs {
     const int* tab_off;                 // null or [A + 1]: per-arena edge tables (see StepArgs)
     float* obs;
     int A, N, K, S, bpa;  // bpa = workgroups per arena = ceil(N / 16)
+    int paircap;          // entries of an agent's (source, ray) pair list: 16 rays x (K + S) sources
     int a0;               // first arena of this launch
     unsigned long long* dbg;  // CA_STAMPS diagnostic build only: [waves][16] phase time stamps
     float radius;         // of the octagon = agent radius (env.py:31,338)
@@ -52,14 +53,13 @@ struct ObsArgs {
 #endif
 // The observation workgroup: OBS_BS lanes = OBS_BS/16 agents of ONE arena (template parameter: 256,
 // 512 or 1024 lanes, so that a workgroup can own a whole arena of up to 64 agents and stage it once).
-constexpr int OBS_PAIRCAP = 16 * (16 + 8);  // (source, ray) pairs of one agent: <= 16 rays x (K + S) sources
 
-// LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | hit points [16][16] float2 | agent frames [16] float4 | nb idx [16][16] | obstacle idx [16][8]
-//              | ray and octagon tables [64] | pair counts [2][16] | (source, ray) pair lists [16][384] u16
+// LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | hit points [16][16] float2 | agent frames [16] float4 | nb idx [16][16] | obstacle idx [16][16]
+//              | ray and octagon tables [64] | pair counts [2][16] | (source, ray) pair lists [16][16 (K + S)] u16
 //              (a list holds the agent-neighbour pairs from its front and the obstacle pairs from its back)
-__host__ __device__ inline size_t obs_lds_bytes(int N, int obs_bs) {
+__host__ __device__ inline size_t obs_lds_bytes(int N, int obs_bs, int paircap) {
     const size_t apb = obs_bs / 16;
-    return (size_t)N * 16 + 2 * apb * 16 * 8 + apb * 16 + apb * 16 * 4 + apb * 8 * 4 + 64 * 4 + 2 * apb * 4 + apb * OBS_PAIRCAP * 2;
+    return (size_t)N * 16 + 2 * apb * 16 * 8 + apb * 16 + apb * 16 * 4 + apb * 16 * 4 + 64 * 4 + 2 * apb * 4 + apb * (size_t)paircap * 2;
 }
 #ifndef CA_OBS_BS_MAX
 #define CA_OBS_BS_MAX 256
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     const int tid = threadIdx.x;
     const int g = tid >> 4, r = tid & 15;
     const int N = p.N, K = p.K, S = p.S;
+    const int PAIRCAP = p.paircap;
     const int ab = blockIdx.x / p.bpa;
     const int a = p.a0 + ab;
     const int i = (blockIdx.x - ab * p.bpa) * OBS_APB + g;
@@ -124,11 +125,11 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     float4* s_frame = reinterpret_cast<float4*>(s_hit + OBS_APB * 16);           // (cos, sin, pos x, pos y) per agent
     int* s_nb = reinterpret_cast<int*>(s_frame + OBS_APB);
     int* s_ob = s_nb + OBS_APB * 16;
-    float* s_rays = reinterpret_cast<float*>(s_ob + OBS_APB * 8);  // [32] rays then [32] octagon
+    float* s_rays = reinterpret_cast<float*>(s_ob + OBS_APB * 16);  // [32] rays then [32] octagon
     float* s_oct = s_rays + 32;
     int* s_cnt = reinterpret_cast<int*>(s_oct + 32);                       // [16] neighbour pairs per agent
     int* s_cnt2 = s_cnt + OBS_APB;                                         // [16] obstacle pairs per agent
-    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_cnt2 + OBS_APB);  // [16][OBS_PAIRCAP]
+    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_cnt2 + OBS_APB);  // [16][paircap]
     CA_OSTAMP(0);
     if (tid < 32) { s_rays[tid] = p.rays[tid]; s_oct[tid] = p.oct[tid]; }
 
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         nn = cnts & 0xFF; ns = cnts >> 8;
         c = p.orient_x[q]; s = -p.orient_y[q];  // utils.py:48-51: cos/sin of -atan2(orientation)
         if (r < nn) s_nb[g * 16 + r] = ld_idx_t<NW16>(p.nb_idx, ((size_t)a * K + r) * N + i);
-        if (r < ns) s_ob[g * 8 + r] = (int)p.obst_idx[((size_t)a * S + r) * N + i];
+        if (r < ns) s_ob[g * 16 + r] = (int)p.obst_idx[((size_t)a * S + r) * N + i];
     }
     s_key[g * 16 + r] = ~0ull;
     if (r == 0) { s_cnt[g] = 0; s_cnt2[g] = 0; }
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         if (w > 0) {  // neighbour pairs fill the list from the front (list order is irrelevant: commutative minimum)
             const int base = atomicAdd(&s_cnt[g], w);
             for (int t2 = 0; t2 < w; ++t2)
-                s_pair[g * OBS_PAIRCAP + base + t2] = (unsigned short)((k << 4) | ((i0 + t2) & 15));
+                s_pair[g * PAIRCAP + base + t2] = (unsigned short)((k << 4) | ((i0 + t2) & 15));
         }
     }
     // (2) lane per RAY, one obstacle edge at a time: the exact test can accept a ray only if the ray's line
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         const float dx = s_rays[2 * r], dy = s_rays[2 * r + 1];
         int cnt2 = 0;
         for (int sidx = 0; sidx < ns; ++sidx) {
-            const ObstDev o1 = load_obst(tab, s_ob[g * 8 + sidx]);
+            const ObstDev o1 = load_obst(tab, s_ob[g * 16 + sidx]);
             const float x1 = o1.px - mx, y1 = o1.py - my, x2 = o1.qx - mx, y2 = o1.qy - my;
             const float ax = c * x1 - s * y1, ay = s * x1 + c * y1;
             const float bx = c * x2 - s * y2, by = s * x2 + c * y2;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             const bool keep = !(c2 > tolE && c3 > tolE) && !(c2 < -tolE && c3 < -tolE) && (fmaxf(f2, f3) >= -tolE);
             const unsigned grp = (unsigned)(__ballot(keep) >> (threadIdx.x & 48)) & 0xFFFFu;  // my agent's 16 lanes
             if (keep)
-                s_pair[g * OBS_PAIRCAP + OBS_PAIRCAP - 1 - (cnt2 + __popc(grp & ((1u << r) - 1u)))] =
+                s_pair[g * PAIRCAP + PAIRCAP - 1 - (cnt2 + __popc(grp & ((1u << r) - 1u)))] =
                     (unsigned short)(((nn + sidx) << 4) | r);
             cnt2 += __popc(grp);
         }
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             x2 = oc.z + rx; y2 = oc.w + ry;
             if (want_vel) { vx = s_vx[nb]; vy = s_vy[nb]; }  // env.py:252
         } else {
-            const ObstDev o1 = load_obst(tab, s_ob[g * 8 + (m - 8 * nn)]);
+            const ObstDev o1 = load_obst(tab, s_ob[g * 16 + (m - 8 * nn)]);
             x1 = o1.px - mx; y1 = o1.py - my;
             x2 = o1.qx - mx; y2 = o1.qy - my;
         }
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
           const bool b1 = b && li >= n1; ga = b1 ? g0 + 2 : ga; li = b1 ? li - n1 : li;
           const bool b2 = b1 && li >= n2; ga = b2 ? g0 + 3 : ga; li = b2 ? li - n2 : li; }
         const float4 fr = s_frame[ga];
-        const int pr = s_pair[ga * OBS_PAIRCAP + li];
+        const int pr = s_pair[ga * PAIRCAP + li];
         const int k = pr >> 4, ray = pr & 15;
         const float s10x = s_rays[2 * ray] - 0.0f, s10y = s_rays[2 * ray + 1] - 0.0f;
         float best = __int_as_float(0x7f800000), bhx = 0.0f, bhy = 0.0f;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     }
     const int no = s_cnt2[g];
     for (int pi = r; pi < no; pi += 16) {
-        const int pr = s_pair[g * OBS_PAIRCAP + OBS_PAIRCAP - 1 - pi];
+        const int pr = s_pair[g * PAIRCAP + PAIRCAP - 1 - pi];
         const int k = pr >> 4, ray = pr & 15;
         const float s10x = s_rays[2 * ray] - 0.0f, s10y = s_rays[2 * ray + 1] - 0.0f;
         SegGeom sg;

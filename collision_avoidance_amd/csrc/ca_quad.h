@@ -230,6 +230,10 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
         touched = touched || active;
         const bool write_lists = (t == T - 1) || (p.flags & 16u) != 0;
 
+        CA_STAMP(0);
+#if defined(CA_STAMPS) && CA_STAMPS == 3
+        CA_STAMP_HWID();   // placement diagnostic: slots 2, 3 = HW_ID, XCC_ID (the phase stamps 2, 3 are skipped below)
+#endif
         // ---- preferred velocity of this step (env.py:371-383) and the arena image ----
         V2 pf32 = mk(1.0f, 0.0f);
         if (active && p.actions) {
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
         if (q == 0) { s_px[slot] = pos.x; s_py[slot] = pos.y; s_vx[slot] = vel.x; s_vy[slot] = vel.y; }
         __syncthreads();
 
+        CA_STAMP(1);
         // ---- obstacle neighbours (App. A.2): edges e = q, q + 4, ... ----
         double okey[SQ];
 #pragma unroll
@@ -269,6 +274,9 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
         const int ocnt = oin < S ? oin : S;
         if (oin > S && q == 0) acc_ovf += 1;
 
+#if !defined(CA_STAMPS) || CA_STAMPS != 3
+        CA_STAMP(2);
+#endif
         // ---- agent neighbours (App. A.2): candidates j = q, q + 4, ... ----
         double nkey[M];
 #pragma unroll
@@ -302,6 +310,9 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
                 if ((k & 3) == q && k < S) p.obst_idx[((size_t)a * S + k) * N + i] = (unsigned short)key_index(okey[k]);
         }
 
+#if !defined(CA_STAMPS) || CA_STAMPS != 3
+        CA_STAMP(3);
+#endif
         // ---- obstacle ORCA lines (App. A.3): lane q builds the line of obstacle neighbour q ----
         int no = 0;
         {
@@ -344,6 +355,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
             no = __popc(qm);
             if (exists) ls.put(__popc(qm & ((1u << q) - 1u)), Line{mk(lpx, lpy), mk(ldx, ldy)});
         }
+        CA_STAMP(4);
         // ---- agent ORCA lines (App. A.4): lane q builds the lines of neighbours q, q + 4, ... ----
         {
             const float invT = 1.0f / p.time_horizon;
@@ -359,10 +371,12 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
             });
         }
         wave_lds_sync();
+        CA_STAMP(5);
         // ---- 2-D linear program (App. A.5) ----
         const int nl = active ? no + ncnt : 0;
         V2 nv = mk(0.0f, 0.0f);
         const int fail = lp2_quad(ls, nl, q, p.max_speed, pref, nv);
+        CA_STAMP(6);
         {   // LP3 for the quads whose LP2 was infeasible: their slot already holds the lines
             const bool need = fail < nl;
             if (__ballot(need) != 0ull) {
@@ -377,6 +391,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
             vel = nv;
             pos = pos + vel * p.time_step;
         }
+        CA_STAMP(7);
         // ---- epilogue (ca_step.h, same order of operations) ----
         __syncthreads();  // every lane is done with the pre-step arena image
         if (q == 0) { s_px[slot] = pos.x; s_py[slot] = pos.y; }
@@ -402,6 +417,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
                 if (walls) atomicAdd(&red[2], 1);
             }
         }
+        CA_STAMP(8);
         // ---- reward (env.py:389-400) or preferred velocity towards the goal (env.py:449) ----
         float rew = 0.0f;
         if (active) {
@@ -417,6 +433,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
                 pref = mk((float)dx, (float)dy);
             }
         }
+        CA_STAMP(9);
         // ---- step counter and done test (env.py:352-365, 404-410; ALAN:118-121, 547-566) ----
         bool goal_changed = false;
         if (active && !p.actions && !nodone) ++steps;
@@ -469,6 +486,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
             pref_dir64(pos.x, pos.y, gx, gy, &dx, &dy);
             pref = mk((float)dx, (float)dy);
         }
+        CA_STAMP(10);
         // sum of rewards: the fixed-shape tree of ca_step.h over agent slots (one lane per slot here)
         if (p.actions && (p.flags & 2u)) {
             if (q == 0) s_rew[slot] = active ? (double)rew : 0.0;
@@ -506,6 +524,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
             if (do_reset) { steps = 0; epi += 1; }
         }
         // (the next step's first barrier separates these reads of red[] from its clearing)
+        CA_STAMP(11);
     }
 
     // ---- write the state back, once ----

@@ -31,10 +31,11 @@ typedef const __attribute__((address_space(4))) StepCold ColdK;  // the cold blo
 template <int KMAX, int BS, int ST, bool FUSE>
 __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs p) {
     extern __shared__ float4 smem4[];
+    CA_PRIO_START();
     // FUSE: the neighbour search runs at the head of this kernel instead of in a launch of its own (one
     // drain/fill less per step, and its dispatch skew overlaps useful work).  A lane later reads back only the
     // lists of its own agent, which it wrote itself; the search's LDS arrays are not used again.
-    if constexpr (FUSE) nbr_body<KMAX, BS>(p);
+    if constexpr (FUSE) nbr_body<KMAX, BS, (ST > 0 ? ST : SMAX)>(p);
     constexpr int ML = ST + KMAX;  // register slots (ST > 0)
     const int tid = threadIdx.x;
     const int P = p.P;
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     __syncthreads();
 
     CA_STAMP(1);
+    CA_PRIO_POINT(1);
     // ---- neighbour lists of this step (App. A.2), produced by nbr_kernel ----
     // (the list pointers as scalars of their own: left inside the 16-register tuple their kernel-argument load
     // arrives in, every use after a spill reloads the whole tuple -- 16 v_readlane for one pointer)
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
 #else
         CA_STAMP(4);
 #endif
+        CA_PRIO_POINT(2);
         {
             const float invT = 1.0f / p.time_horizon;
             const float invDt = 1.0f / p.time_step;
@@ -163,11 +166,13 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
             });
         }
         CA_STAMP(5);
+        CA_PRIO_POINT(3);
         // ---- 2-D linear program (App. A.5) on the register slots ----
         const int nl = no + ncnt;
         int fail = nl;
         if (active) fail = lp2_reg<ML, ST>(L, no, ncnt, p.max_speed, pref, nv);
         CA_STAMP(6);
+        CA_PRIO_POINT(5);
         // ---- LP3 for the lanes whose LP2 was infeasible: they copy their lines into a slot of the
         // wave's LDS pool and solve there; more than POOL_SLOTS such lanes take further rounds ----
         {
@@ -258,6 +263,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
         pos = mk(s_px[tid], s_py[tid]) + vel * p.time_step;  // own pre-step position: still in the staged arena
     }
     CA_STAMP(7);
+    CA_PRIO_POINT(6);
     // ---- epilogue.  Its indices are derived afresh from the lane id (behind an opaque move, so that the compiler
     // cannot keep the prologue's copies -- 64-bit element offsets, LDS addresses -- alive across the solve, where
     // they would be spilled to scratch); the names shadow the prologue's on purpose. ----
@@ -339,6 +345,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs
     }
 
     CA_STAMP(8);
+    CA_PRIO_POINT(7);
     // ---- reward (env.py:389-400) or preferred velocity towards the goal (env.py:449) ----
     float rew = 0.0f;
     double gx = 0.0, gy = 0.0;

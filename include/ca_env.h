@@ -30,7 +30,8 @@ extern "C" {
 #define CA_OBS_DIM 64 /* env.py:34,53: 16 rays x (hit x, hit y, vel x, vel y) */
 #define CA_N_RAYS 16
 #define CA_MAX_NEIGHBORS 16      /* largest supported max_neighbors       */
-#define CA_MAX_OBST_NEIGHBORS 8  /* largest supported max_obst_neighbors  */
+#define CA_MAX_OBST_NEIGHBORS 16 /* largest supported max_obst_neighbors: RVO2 keeps every edge in range (env.py:249,
+                                    301-318); 16 covers the reference's own worlds (ca_stats.obst_overflow counts the rest) */
 #define CA_MAX_AGENTS 1024       /* one workgroup owns one arena; above 256 agents max_neighbors <= 10
                                     and max_obst_neighbors <= 4 are required (LDS capacity)              */
 

@@ -29,7 +29,7 @@ def make_oracle(A, N, scenario, params, seed=0, arena_offset=0, max_obst_neighbo
     elif isinstance(polys, dict):
         worlds, polys = list(polys["per_arena"]), []
     n_edges = max(sum(len(q) for q in w) for w in worlds) if worlds else sum(len(q) for q in polys)
-    S = max(1, min(8, n_edges)) if max_obst_neighbors is None else max_obst_neighbors
+    S = max(1, min(16, n_edges)) if max_obst_neighbors is None else max_obst_neighbors
     cfg = o.make_config(n_arenas=A, n_agents=N, seed=seed, arena_offset=arena_offset,
                         max_obst_neighbors=S, **params)
     env = o.OracleEnv(cfg)

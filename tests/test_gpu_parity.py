@@ -111,6 +111,23 @@ def test_orca_rollout_bit_exact(name, A, N, scenario, over, steps, every):
     gpu.close()
 
 
+@pytest.mark.parametrize("scenario,N", [("deadlock", 20), ("deadlock", 30), ("blocks", 12), ("doorway", 10), ("congested", 24),
+                                        ("incoming", 17), ("crowd", 16), ("circle", 12)])
+def test_reference_worlds_keep_every_obstacle_edge_in_range(scenario, N):
+    """RVO2 keeps EVERY obstacle edge in range (env.py:249, 301-318 read them all); the obstacle-neighbour list here has a
+    capacity (16, the default for worlds with that many edges): in the reference's own seven worlds (env.py:77-123,
+    ALAN:175-457) no agent-step may lose an edge -- with a capacity of 8 the two-way tube of "deadlock" dropped the
+    farthest edges in 0.6 % of the agent-steps (profiles/r02_soak_parity.txt)."""
+    p = H.scenario_params(scenario, N)
+    gpu = H.make_gpu(8, N, scenario, p, seed=3)
+    orc = H.make_oracle(8, N, scenario, p, seed=3)
+    gpu.rollout(1500, stats=True)
+    orc.rollout(1500, flags=o.F_STATS, n_threads=8)
+    H.assert_state_equal(gpu, orc, scenario)
+    H.assert_stats_equal(gpu, orc, scenario)
+    assert gpu.stats()["obst_overflow"] == 0 and orc.stats()["obst_overflow"] == 0
+
+
 def test_obs_adversarial_geometry():
     """The observation kernel culls rays by the angular span of each segment; the culling must be a
     superset of what the exact test accepts.  Neighbours are placed exactly on ray directions, on

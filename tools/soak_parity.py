@@ -36,6 +36,7 @@ for scen, N, p, seed in cases:
         if s % 50 == 49 or s == steps - 1:
             H.assert_state_equal(g, e, "%s N=%d step %d" % (scen, N, s), obs=True, reward=True)
     H.assert_stats_equal(g, e, scen)
+    assert g.stats()["obst_overflow"] == 0, "an obstacle-neighbour list overflowed in %s" % scen
     print("ok  %-9s A=%d N=%d steps=%d seed=%d  (%.1f s)  stats %s" % (scen, A_case, N, steps, seed, time.time() - t0, g.stats()), flush=True)
     g.close()
 print("soak passed")

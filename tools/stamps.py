@@ -31,6 +31,9 @@ env.L.ca_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C
 rng = np.random.RandomState(0)
 names = ["load+pref+stage", "list counts", "(unused)", "obst lines", "agent lines", "LP2", "LP3+integrate",
          "barrier+stats", "reward/pref", "done test+reduce", "tail sync+write"]
+if env.launch_info()["lanes_per_agent"] == 4:   # the quad kernel stamps its own phases (csrc/ca_quad.h)
+    names = ["pref+stage arena", "obstacle nbrs+merge", "agent scan+merge+lists", "obst lines", "agent lines", "LP2",
+             "LP3+integrate", "barriers+stats", "reward/pref", "done test+reduce", "reset/orient/tail"]
 acc, nacc = [], []
 for s in range(120):
     if mode == "step":
@@ -39,7 +42,7 @@ for s in range(120):
         env.orca_step(stats=True)
     if s >= 100:
         nw = C.c_int32()
-        buf = np.zeros((A * max(1, N // 64) * 2, 16), np.uint64)
+        buf = np.zeros((A * max(1, N // 16) * 2, 16), np.uint64)
         env._call("ca_debug_stamps", env.h, buf.ctypes.data, buf.shape[0], C.byref(nw))
         t = buf[:nw.value, :12].astype(np.int64)
         acc.append(np.diff(t, axis=1))
@@ -86,6 +89,8 @@ print("%s %s: %d waves sampled, mean cycles/wave %.0f (p50 %.0f, p95 %.0f)" %
 for k, n in enumerate(names):
     print("  %-18s %8.0f cycles  %5.1f %%   (p95 %6.0f)" % (n, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean(),
                                                            np.percentile(d[:, k], 95)))
+if env.launch_info()["lanes_per_agent"] == 4:
+    raise SystemExit(0)
 nd = np.concatenate(nacc)
 print("nbr_kernel: %d waves sampled, mean cycles/wave (first to last stamp) %.0f" % (len(nd), nd.sum(axis=1).mean()))
 for k, n in enumerate(["load+stage+obstacle edges", "agent scan", "list stores"]):
