@@ -139,14 +139,14 @@ __device__ __forceinline__ ObstDev load_obst(const ObstDev* __restrict__ t, int 
 // Wave priority by progress (step_kernel): the four waves that share a SIMD are served oldest first, so they finish one
 // after the other and the last one runs alone -- at a lone wave's issue rate -- for the final fifth of the kernel.  A wave
 // that LOWERS its priority at each phase boundary lets the waves behind it catch up, so the four stay within a phase of
-// each other and finish together (C3: step_kernel 81.8 -> 73.7 us; profiles/r03_b_wave_priority_experiment.txt).
+// each other and finish together (C3: step_kernel 81.9 -> 71.2 us; profiles/r03_b_wave_priority_experiment.txt).
 // Points along step_kernel: 1 after the neighbour search, 2 after the obstacle lines, 3 after the agent lines, 4 in the
 // middle of LP2, 5 after LP2, 6 after LP3 + integration, 7 after the collision statistics.  A wave starts at priority 3
 // and drops to 2, 1, 0 at the points CA_PRIO_B1 < CA_PRIO_B2 < CA_PRIO_B3 (0 = never: no priority instructions at all).
 #ifndef CA_PRIO_B1
 #define CA_PRIO_B1 2
-#define CA_PRIO_B2 3
-#define CA_PRIO_B3 5
+#define CA_PRIO_B2 4
+#define CA_PRIO_B3 6
 #endif
 #if CA_PRIO_B1 > 0
 #define CA_PRIO_START() __builtin_amdgcn_s_setprio(3)
