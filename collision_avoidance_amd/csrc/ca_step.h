@@ -28,8 +28,11 @@ __host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S, int ST = 
 //         of the C3 workload are all resident at once instead of taking 1.6 rounds at 10 per CU.
 typedef const __attribute__((address_space(4))) StepCold ColdK;  // the cold block through the constant address space
 
+#ifndef CA_LB512
+#define CA_LB512 4   // waves per SIMD the 512-lane register-line kernel is built for (diagnostic: 2 = 256 VGPRs)
+#endif
 template <int KMAX, int BS, int ST, bool FUSE>
-__global__ __launch_bounds__(BS, ST > 0 ? 4 : 1) void step_kernel(const StepArgs p) {
+__global__ __launch_bounds__(BS, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1) void step_kernel(const StepArgs p) {
     extern __shared__ float4 smem4[];
     CA_PRIO_START();
     // FUSE: the neighbour search runs at the head of this kernel instead of in a launch of its own (one
