@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 from collision_avoidance_amd import build as b  # noqa: E402
 
 KERNELS = ("nbr_kernel", "step_kernel", "obs_kernel", "lp3_kernel")
+ALIAS = {"quad_kernel": "step_kernel"}   # the four-lanes-per-agent solve kernel is reported in the step_kernel slot (its full name is kept)
 
 
 def means(d):
@@ -28,10 +29,11 @@ def means(d):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            for name in KERNELS:
+            for name in KERNELS + tuple(ALIAS):
                 if name in k:
-                    acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                    names[name] = k.split("(")[0].replace("void ca::", "")
+                    key = ALIAS.get(name, name)
+                    acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    names[key] = k.split("(")[0].replace("void ca::", "")
     return ({k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()},
             {k: max(len(v) for v in d.values()) for k, d in acc.items()}, names)
 

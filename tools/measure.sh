@@ -10,7 +10,16 @@ timeout -k 10 300 python3 $R/bench.py > $O/${T}_bench_C3_step.json 2>$O/bench.er
 python3 -c "import json;d=json.load(open('$O/${T}_bench_C3_step.json'));print('C3 step', d['value'], d['kernels_ms'], d['roofline']['kernel'], d['roofline']['frac'])"
 [ "$2" = quick ] && exit 0
 for wl in C2 C5; do timeout -k 10 300 python3 $R/bench.py --workload $wl > $O/${T}_bench_$wl.json 2>>$O/bench.err || exit 1; done
-timeout -k 10 300 python3 $R/bench.py --mode orca > $O/${T}_bench_C3_orca.json 2>>$O/bench.err || exit 1
+# ORCA-only policy rollouts (BASELINE config C2 is one): ca_rollout in chunks of 50 steps, and one ca_orca_step per step
+for wl in C2 C3 C5; do
+  timeout -k 10 300 python3 $R/bench.py --workload $wl --mode orca > $O/${T}_bench_${wl}_orca.json 2>>$O/bench.err || exit 1
+  timeout -k 10 300 python3 $R/bench.py --workload $wl --mode orca --rollout-chunk 1 --no-cpu-baseline > $O/${T}_bench_${wl}_orca_per_step_calls.json 2>>$O/bench.err || exit 1
+done
+python3 - <<PY
+import json,glob
+for f in sorted(glob.glob("$O/${T}_bench_*.json")):
+    d=json.load(open(f)); print("%-48s %8.1f M  %s" % (f.split("/")[-1], d["value"]/1e6, d["kernels_ms"]))
+PY
 timeout -k 10 300 python3 $R/bench.py --variant free --no-cpu-baseline > $O/${T}_bench_C3_step_free.json 2>>$O/bench.err || exit 1
 timeout -k 10 300 python3 $R/bench.py --starts separated --no-cpu-baseline > $O/${T}_bench_C3_step_separated.json 2>>$O/bench.err || exit 1
 timeout -k 10 600 python3 $R/tools/cpu_baseline_table.py $O/${T}_cpu_baseline_table.json 4 > $O/${T}_cpu_baseline_table.txt 2>>$O/bench.err || exit 1
