@@ -87,6 +87,30 @@ def launch_ranks(args):
     raise SystemExit(0)
 
 
+def host_cores():
+    """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box shows all
+    256 hardware threads of the host but gives a one-GPU job a share of them: threads beyond the quota only time-slice)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if t[0] != "max":
+                    n = min(n, max(1, int(int(t[0]) / int(t[1]) + 0.5)))
+            else:
+                q = int(t[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(workload, mode, seconds, variant="walls", starts="overlap"):
     """The CPU oracle (a C++ restatement of the same path) on a bounded sample of the same workload: arenas of the
     same scenario stepped for about `seconds`, first on one core, then on all cores of this process's share of
@@ -98,10 +122,7 @@ def cpu_baseline(workload, mode, seconds, variant="walls", starts="overlap"):
     from tests import helpers as H
     w = scenarios.BENCH_CONFIGS[workload]
     N = w["n_agents"]
-    try:
-        cores = max(1, len(os.sched_getaffinity(0)))
-    except Exception:
-        cores = max(1, os.cpu_count() or 1)
+    cores = host_cores()
     rng = np.random.RandomState(0)
     scn = "crowd" if starts == "overlap" else "crowd_separated"
     flags = o.F_OBS if mode == "step" else 0
@@ -205,6 +226,7 @@ def main():
     if args.steps % chunk or args.warmup % chunk:
         raise SystemExit("bench.py: --steps and --warmup must be multiples of --rollout-chunk (%d)" % chunk)
     lanes_per_agent = env.launch_info()["lanes_per_agent"]
+    obs_fused = bool(env.launch_info()["obs_fused"]) and full   # (four-lanes kernel: the observation is written by the same launch)
     steps_per_launch = chunk if lanes_per_agent == 4 else 1   # (one lane per agent: ca_rollout is a loop of launches)
 
     def one_step(i):  # the production call: one ca_step (neighbours -> ORCA solve -> observation) ...
@@ -259,6 +281,8 @@ def main():
         value = world * agents * args.steps / dt
         kbytes_of = {"nbr_kernel": 0, "step_kernel": BYTES_STEP_KERNEL_FULL if full else BYTES_STEP_KERNEL_ORCA,
                      "obs_kernel": BYTES_OBS_KERNEL}
+        if obs_fused:
+            kbytes_of["step_kernel"] += BYTES_OBS_KERNEL
         kms_of = {k: v[1] / (steps_per_launch if k == "step_kernel" else 1) for k, v in ktimes.items() if v[0] > 0 and k in kbytes_of}
         # dominant kernel: strictly the longest average launch (no tie-break)
         dom = max(kms_of, key=lambda k: kms_of[k])
@@ -307,6 +331,7 @@ def main():
                                     "boundary walls" if args.variant == "walls" else "obstacle-free", args.starts),
                        "mode": args.mode, "variant": args.variant, "starts": args.starts,
                        "rollout_chunk": chunk, "steps_per_launch": steps_per_launch, "lanes_per_agent": lanes_per_agent,
+                       "obs_fused_into_step_launch": obs_fused,
                        "sharding": "arenas, %d per GPU" % A},
             "world_size": world,
             "ranks": [{"rank": r, "device": d["device"], "agent_steps": d["agent_steps"]}

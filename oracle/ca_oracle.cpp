@@ -278,7 +278,8 @@ void lp3(const std::vector<Line>& lines, int numObst, int begin, float radius, V
     float distance = 0.0f;
     for (int i = begin; i < (int)lines.size(); ++i) {
         if (det(lines[i].dir, lines[i].point - result) > distance) {
-            std::vector<Line> proj(lines.begin(), lines.begin() + numObst);
+            static thread_local std::vector<Line> proj;
+            proj.assign(lines.begin(), lines.begin() + numObst);
             for (int j = numObst; j < i; ++j) {
                 Line l;
                 const float d = det(lines[i].dir, lines[j].dir);
@@ -307,7 +308,8 @@ static uint64_t g_dbg[4] = {0, 0, 0, 0};
 void compute_new_velocity(Arena& a, const std::vector<ObstVertex>& obst, int i, float timeStep) {
     const AgentParams& P = a.prm[i];
     const V2 pos = a.pos[i], vel = a.vel[i];
-    std::vector<Line> lines;
+    static thread_local std::vector<Line> lines;  /* reused: no allocation per agent-step */
+    lines.clear();
     const float invTO = 1.0f / P.timeHorizonObst;
     const float R = P.radius;
 
@@ -697,7 +699,8 @@ inline T ray_flip_margin(T rx, T ry, const Seg<T>* rot, int m) {
 
 template <class T>
 void comp_laser(const T* rays, const Seg<T>* segs, int m, T c, T s, T* out, double* margin = nullptr) {
-    std::vector<Seg<T> > rot(m);
+    static thread_local std::vector<Seg<T> > rot;  /* reused: no allocation per agent-step (the multi-core baseline) */
+    rot.resize(m);
     for (int k = 0; k < m; ++k) {
         const Seg<T>& g = segs[k];
         const T lvx = g.x1 + g.vx, lvy = g.y1 + g.vy;           /* utils.py:57 */
@@ -781,7 +784,8 @@ void agent_obs(Env& e, int a, int i, T* out, double* margin = nullptr) {
     const int N = e.N();
     const T* oct = (sizeof(T) == 8) ? (const T*)(const void*)e.oct64 : (const T*)(const void*)e.oct32;
     const T* rays = (sizeof(T) == 8) ? (const T*)(const void*)e.rays64 : (const T*)(const void*)e.rays32;
-    std::vector<Seg<T> > segs;
+    static thread_local std::vector<Seg<T> > segs;
+    segs.clear();
     const V2 me = ar.pos[i];
     for (size_t k = 0; k < ar.agentNb[i].size(); ++k) { /* env.py:283-294 */
         const int nb = ar.agentNb[i][k].second;

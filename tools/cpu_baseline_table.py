@@ -16,10 +16,8 @@ from oracle import oracle as o
 from tests import helpers as H
 
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
-try:
-    cores = max(1, len(os.sched_getaffinity(0)))
-except Exception:
-    cores = os.cpu_count() or 1
+import bench as _bench   # host_cores(): affinity capped by the cgroup CPU quota
+cores = _bench.host_cores()
 rng = np.random.RandomState(0)
 
 
@@ -56,9 +54,10 @@ for wl in ("C2", "C3", "C5"):
         A1 = max(1, min(64, 4096 // N))
         rows.append(dict(config="%s %dx%d" % (wl, w["n_arenas"], N), mode=mode,
                          **run(H.make_oracle(A1, N, "crowd", p, seed=0), A1, N, mode, 1)))
-        Am = cores * max(1, min(16, 1024 // N))   # every thread owns a block of whole arenas
-        rows.append(dict(config="%s %dx%d" % (wl, w["n_arenas"], N), mode=mode,
-                         **run(H.make_oracle(Am, N, "crowd", p, seed=0), Am, N, mode, cores)))
+        for th in sorted(set([min(16, cores), cores])):   # 16 = the CPU share of a one-GPU job on this pool
+            Am = th * max(1, min(16, 1024 // N))   # every thread owns a block of whole arenas
+            rows.append(dict(config="%s %dx%d" % (wl, w["n_arenas"], N), mode=mode,
+                             **run(H.make_oracle(Am, N, "crowd", p, seed=0), Am, N, mode, th)))
 cpu = ""
 try:
     cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
