@@ -492,9 +492,10 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->BSq = 4 * P > 64 ? 4 * P : 64;
         const int apbq = (e->BSq / 4) / P;
         e->grid_q = (cfg->n_arenas + apbq - 1) / apbq;
-        e->lds_q = quad_lds_bytes(e->BSq, e->KT, e->K, e->S);
         const char* fo = getenv("CA_FUSE_OBS");  // diagnostic switch: 0 = observation as a launch of its own
-        e->fuse_obs = !(fo && fo[0] == '0');
+        // the fused observation keeps ~13 KB of tables per wave: only up to 256-lane workgroups (<= 64 agents per arena)
+        e->fuse_obs = !(fo && fo[0] == '0') && quad_lds_bytes(e->BSq, e->KT, e->K, e->S, true) <= 96 * 1024;
+        e->lds_q = quad_lds_bytes(e->BSq, e->KT, e->K, e->S, e->fuse_obs);
     }
     // + the statically allocated LDS of the fused neighbour search: positions, and for >= 256 lanes the grid tables
     const size_t lds_static = (size_t)e->BS * 8 + (e->BS >= 256 ? (size_t)e->BS * 2 + 16 + 1024 + 1028 : 0) + 64;

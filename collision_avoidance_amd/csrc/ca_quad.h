@@ -156,10 +156,10 @@ __device__ __forceinline__ int lp2_quad(const LdsLines& ls, int n, int q, float 
 
 // LDS of the quad kernel (bytes): line table [waves][2 ML][16] float4 | px py vx vy [BS/4] | per-arena reductions
 // [BS/4][4] int | rewards [BS/4] double | ray + octagon tables [64] float | observation tables per wave (ca_quad_obs.h)
-__host__ __device__ inline size_t quad_lds_bytes(int BS, int KMAX, int K, int S) {
+__host__ __device__ inline size_t quad_lds_bytes(int BS, int KMAX, int K, int S, bool with_obs) {
     const size_t ns = (size_t)BS / 4;
     return (size_t)(BS / 64) * (2 * (4 + KMAX)) * POOL_SLOTS * 16 + ns * 16 + ns * 16 + ns * 8 + 256 +
-           (size_t)(BS / 64) * quad_obs_lds_per_wave(K, S);
+           (with_obs ? (size_t)(BS / 64) * quad_obs_lds_per_wave(K, S) : 0);
 }
 
 template <int KMAX, int BS>

@@ -95,7 +95,7 @@ def test_quad_observation_fused_or_not_equals_oracle(scenario, N, over, fuse):
         A = 21
         p = H.scenario_params(scenario, N, **over)
         gpu = H.make_gpu(A, N, scenario, p, seed=9)
-        assert gpu.launch_info()["obs_fused"] == int(fuse) and _is_quad(gpu)
+        assert gpu.launch_info()["obs_fused"] == int(fuse) and _is_quad(gpu), gpu.launch_info()
         orc = H.make_oracle(A, N, scenario, p, seed=9)
         rng = np.random.RandomState(9)
         for s in range(120):
