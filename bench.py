@@ -226,7 +226,6 @@ def main():
     if args.steps % chunk or args.warmup % chunk:
         raise SystemExit("bench.py: --steps and --warmup must be multiples of --rollout-chunk (%d)" % chunk)
     lanes_per_agent = env.launch_info()["lanes_per_agent"]
-    obs_fused = bool(env.launch_info()["obs_fused"]) and full   # (four-lanes kernel: the observation is written by the same launch)
     steps_per_launch = chunk if lanes_per_agent == 4 else 1   # (one lane per agent: ca_rollout is a loop of launches)
 
     def one_step(i):  # the production call: one ca_step (neighbours -> ORCA solve -> observation) ...
@@ -281,8 +280,6 @@ def main():
         value = world * agents * args.steps / dt
         kbytes_of = {"nbr_kernel": 0, "step_kernel": BYTES_STEP_KERNEL_FULL if full else BYTES_STEP_KERNEL_ORCA,
                      "obs_kernel": BYTES_OBS_KERNEL}
-        if obs_fused:
-            kbytes_of["step_kernel"] += BYTES_OBS_KERNEL
         kms_of = {k: v[1] / (steps_per_launch if k == "step_kernel" else 1) for k, v in ktimes.items() if v[0] > 0 and k in kbytes_of}
         # dominant kernel: strictly the longest average launch (no tie-break)
         dom = max(kms_of, key=lambda k: kms_of[k])
@@ -331,7 +328,6 @@ def main():
                                     "boundary walls" if args.variant == "walls" else "obstacle-free", args.starts),
                        "mode": args.mode, "variant": args.variant, "starts": args.starts,
                        "rollout_chunk": chunk, "steps_per_launch": steps_per_launch, "lanes_per_agent": lanes_per_agent,
-                       "obs_fused_into_step_launch": obs_fused,
                        "sharding": "arenas, %d per GPU" % A},
             "world_size": world,
             "ranks": [{"rank": r, "device": d["device"], "agent_steps": d["agent_steps"]}

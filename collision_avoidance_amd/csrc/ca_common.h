@@ -45,7 +45,6 @@ struct StepCold {
     int max_step, done_mode;
     float done_x_thresh;
     float spawn_x0, spawn_x1, spawn_y0, spawn_y1, goal_x0, goal_x1, goal_y0, goal_y1;
-    float obs_tab[64];  // [32] ray end points (env.py:321-332), [32] octagon chords (env.py:335-350): the quad kernel's fused observation
 };
 
 struct StepArgs {
@@ -74,7 +73,6 @@ struct StepArgs {
     int n_obst, A, N, P, logP, K, S;
     int a0, a1;  // this launch covers arenas [a0, a1) (chunked launches on several streams)
     int T;       // quad kernel, ORCA-only mode: steps advanced by this launch (ca_quad.h); 1 otherwise
-    float* obs;  // quad kernel: non-null = write the observation of the final state in the same launch (ca_quad_obs.h)
     uint32_t flags;
     float time_step, neighbor_dist, time_horizon, time_horizon_obst, radius, max_speed;
 };

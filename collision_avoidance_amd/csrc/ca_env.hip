@@ -62,7 +62,6 @@ struct ca_env {
     bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
     int ST = 0, KT = 16;  // solve-kernel variant: ST > 0 = register lines with ST obstacle slots; KT = KMAX
     bool quad = false;     // four lanes per agent (ca_quad.h): small batches / small arenas
-    bool fuse_obs = true;  // quad kernel: the observation in the same launch (ca_quad_obs.h)
     int BSq = 64, grid_q = 1;
     size_t lds_q = 0;
     size_t lds = 0;
@@ -193,8 +192,6 @@ static void fill_cold(const ca_env* e, StepCold& c) {
     c.max_step = g.max_step; c.done_mode = g.done_mode; c.done_x_thresh = g.done_x_thresh;
     c.spawn_x0 = g.spawn_x0; c.spawn_x1 = g.spawn_x1; c.spawn_y0 = g.spawn_y0; c.spawn_y1 = g.spawn_y1;
     c.goal_x0 = g.goal_x0; c.goal_x1 = g.goal_x1; c.goal_y0 = g.goal_y0; c.goal_y1 = g.goal_y1;
-    memcpy(c.obs_tab, e->rays, sizeof e->rays);
-    memcpy(c.obs_tab + 32, e->oct, sizeof e->oct);
 }
 
 static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t flags) {
@@ -209,7 +206,7 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
 #endif
     a.reset_px = nullptr; a.reset_py = nullptr; a.reset_mask = nullptr; a.dbg = e->dbg;
     a.n_obst = e->h_tab_off.empty() ? (int)e->h_obst.size() : 0; a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
-    a.K = e->K; a.S = e->S; a.flags = flags; a.a0 = 0; a.a1 = c.n_arenas; a.T = 1; a.obs = nullptr;
+    a.K = e->K; a.S = e->S; a.flags = flags; a.a0 = 0; a.a1 = c.n_arenas; a.T = 1;
     a.time_step = c.time_step; a.neighbor_dist = c.neighbor_dist; a.time_horizon = c.time_horizon;
     a.time_horizon_obst = c.time_horizon_obst; a.radius = c.radius; a.max_speed = c.max_speed;
 }
@@ -492,10 +489,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->BSq = 4 * P > 64 ? 4 * P : 64;
         const int apbq = (e->BSq / 4) / P;
         e->grid_q = (cfg->n_arenas + apbq - 1) / apbq;
-        const char* fo = getenv("CA_FUSE_OBS");  // diagnostic switch: 0 = observation as a launch of its own
-        // the fused observation keeps ~13 KB of tables per wave: only up to 256-lane workgroups (<= 64 agents per arena)
-        e->fuse_obs = !(fo && fo[0] == '0') && quad_lds_bytes(e->BSq, e->KT, e->K, e->S, true) <= 96 * 1024;
-        e->lds_q = quad_lds_bytes(e->BSq, e->KT, e->K, e->S, e->fuse_obs);
+        e->lds_q = quad_lds_bytes(e->BSq, e->KT);
     }
     // + the statically allocated LDS of the fused neighbour search: positions, and for >= 256 lanes the grid tables
     const size_t lds_static = (size_t)e->BS * 8 + (e->BS >= 256 ? (size_t)e->BS * 2 + 16 + 1024 + 1028 : 0) + 64;
@@ -998,12 +992,9 @@ static int do_step(ca_env* e, const float* actions, uint32_t flags) {
     if (e->prof_period > 1) e->profiling = (e->steps_done % (uint64_t)e->prof_period) == 0;
     StepArgs a;
     fill_args(e, a, actions, flags);
-    // small batches (quad kernel): the wave that advanced 16 agents also observes for them, no second launch
-    const bool fused = e->quad && e->fuse_obs && (flags & CA_F_OBS) && !(flags & CA_F_FREEZE);
-    if (fused) a.obs = e->obs;
     HIPCHK(e, launch_step(e, a));
     e->orient_valid = true;
-    if ((flags & CA_F_OBS) && !fused) HIPCHK(e, launch_obs(e));
+    if (flags & CA_F_OBS) HIPCHK(e, launch_obs(e));
     e->steps_done += 1;
     return CA_OK;
 }
@@ -1267,10 +1258,9 @@ int ca_launch_info(ca_env* e, int32_t* block, int32_t* grid, int32_t* lds_bytes,
     return CA_OK;
 }
 
-int ca_solver_info(ca_env* e, int32_t* lanes_per_agent, int32_t* obs_fused) {
+int ca_solver_info(ca_env* e, int32_t* lanes_per_agent) {
     if (!e) return CA_EINVAL;
     if (lanes_per_agent) *lanes_per_agent = e->quad ? 4 : 1;
-    if (obs_fused) *obs_fused = (e->quad && e->fuse_obs) ? 1 : 0;
     return CA_OK;
 }
 

@@ -28,7 +28,6 @@
 // kernel); ca_env.hip picks it where one lane per agent would leave the chip short of waves (CA_QUAD=0/1 forces it).
 #pragma once
 #include "ca_step.h"
-#include "ca_quad_obs.h"
 
 namespace ca {
 
@@ -155,11 +154,10 @@ __device__ __forceinline__ int lp2_quad(const LdsLines& ls, int n, int q, float 
 }
 
 // LDS of the quad kernel (bytes): line table [waves][2 ML][16] float4 | px py vx vy [BS/4] | per-arena reductions
-// [BS/4][4] int | rewards [BS/4] double | ray + octagon tables [64] float | observation tables per wave (ca_quad_obs.h)
-__host__ __device__ inline size_t quad_lds_bytes(int BS, int KMAX, int K, int S, bool with_obs) {
+// [BS/4][4] int | rewards [BS/4] double
+__host__ __device__ inline size_t quad_lds_bytes(int BS, int KMAX) {
     const size_t ns = (size_t)BS / 4;
-    return (size_t)(BS / 64) * (2 * (4 + KMAX)) * POOL_SLOTS * 16 + ns * 16 + ns * 16 + ns * 8 + 256 +
-           (with_obs ? (size_t)(BS / 64) * quad_obs_lds_per_wave(K, S) : 0);
+    return (size_t)(BS / 64) * (2 * (4 + KMAX)) * POOL_SLOTS * 16 + ns * 16 + ns * 16 + ns * 8;
 }
 
 template <int KMAX, int BS>
@@ -194,9 +192,6 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
     float* s_vy = s_vx + NS;
     int* s_red = reinterpret_cast<int*>(s_vy + NS);            // [NS][4]; arena la uses row la
     double* s_rew = reinterpret_cast<double*>(s_red + NS * 4);  // [NS]
-    float* s_tab = reinterpret_cast<float*>(s_rew + NS);        // [64] ray end points, octagon chords
-    const QuadObsWave ow = quad_obs_carve(reinterpret_cast<char*>(s_tab + 64) + (size_t)(tid >> 6) * quad_obs_lds_per_wave(K, S), K, S);
-    if (p.obs != nullptr && tid < 64) s_tab[tid] = c.obs_tab[tid];  // (visible after the first barrier of the step)
     int* red = s_red + la * 4;  // per arena: [0] not-done agents, [1] pairs, [2] wall hits, [3] goals
 
     // ---- state of this agent, resident for the whole launch (the four lanes of a quad hold the same values) ----
@@ -304,13 +299,6 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) ncnt += (k < K && key_index(nkey[k]) >= 0) ? 1 : 0;
 
-        if (p.obs != nullptr) {  // the observation of this step reads the lists from the wave's tables (ca_quad_obs.h)
-            static_for<KQ>([&](auto mc) __attribute__((always_inline)) {
-                constexpr int m = decltype(mc)::value;
-                if (4 * m + q < ncnt) ow.nb[wslot * 16 + 4 * m + q] = lbase + pick4_index<4 * m>(nkey, q);
-            });
-            if (q < ocnt) ow.ob[wslot * 4 + q] = tab0 + pick4_index<0>(okey, q);
-        }
         // ---- the lists are state (the reference's reset() observes with the lists of the last doStep) ----
         if (active && write_lists) {
             if (q == 0) p.counts[gq] = (unsigned short)(ncnt | (ocnt << 8));
@@ -537,13 +525,6 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
         }
         // (the next step's first barrier separates these reads of red[] from its clearing)
         CA_STAMP(11);
-        if (p.obs != nullptr) {  // ---- laser observation of the final state (env.py:231-277), same launch ----
-            __syncthreads();
-            if (q == 0) { s_px[slot] = pos.x; s_py[slot] = pos.y; s_vx[slot] = vel.x; s_vy[slot] = vel.y; }
-            __syncthreads();
-            quad_obs<KQ>(ow, in_arena, wslot, q, tid & 63, ncnt, ocnt, ox, oy, pos, s_px, s_py, s_vx, s_vy, p.obst, s_tab,
-                         p.radius, reinterpret_cast<float4*>(p.obs) + (size_t)gq * 16);
-        }
     }
 
     // ---- write the state back, once ----

@@ -252,9 +252,8 @@ int ca_launch_info(ca_env* env, int32_t* block, int32_t* grid, int32_t* lds_byte
  * at ca_create for batches that would otherwise leave the chip short of waves -- fewer than two waves per SIMD -- when
  * n_agents <= 128, max_neighbors <= 10 and max_obst_neighbors <= 4; results are identical bit for bit).  With 4,
  * ca_rollout(env, T, flags without CA_F_OBS) is ONE kernel launch that keeps every arena in registers / LDS for its T
- * steps; otherwise it is T launches.  *obs_fused = 1: ca_step / ca_orca_step with CA_F_OBS write the observation in the
- * same launch as the step (four-lanes kernel; not under CA_F_FREEZE), 0: obs_kernel runs as a second launch. */
-int ca_solver_info(ca_env* env, int32_t* lanes_per_agent, int32_t* obs_fused);
+ * steps; otherwise it is T launches. */
+int ca_solver_info(ca_env* env, int32_t* lanes_per_agent);
 
 #ifdef __cplusplus
 }

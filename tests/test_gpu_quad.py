@@ -83,36 +83,6 @@ def test_quad_step_with_actions_obs_and_autoreset(N, K):
     gpu.close()
 
 
-@pytest.mark.parametrize("fuse", ["1", "0"])
-@pytest.mark.parametrize("scenario,N,over", [("crowd", 16, dict(neighbor_dist=1.5, max_neighbors=5)),
-                                             ("crowd", 64, dict(neighbor_dist=5.0, max_neighbors=10)),
-                                             ("circle", 7, {}), ("crowd", 3, dict(max_neighbors=10)),
-                                             ("crowd_separated", 40, dict(neighbor_dist=3.0, max_neighbors=8))])
-def test_quad_observation_fused_or_not_equals_oracle(scenario, N, over, fuse):
-    """The observation written by the step's own launch (ca_quad_obs.h) and by obs_kernel, both against the oracle."""
-    os.environ["CA_FUSE_OBS"] = fuse
-    try:
-        A = 21
-        p = H.scenario_params(scenario, N, **over)
-        gpu = H.make_gpu(A, N, scenario, p, seed=9)
-        assert gpu.launch_info()["obs_fused"] == int(fuse) and _is_quad(gpu), gpu.launch_info()
-        orc = H.make_oracle(A, N, scenario, p, seed=9)
-        rng = np.random.RandomState(9)
-        for s in range(120):
-            if s % 2:
-                act = rng.uniform(-0.8, 0.8, (A, N)).astype(np.float32)
-                gpu.step(act, stats=True)
-                orc.step(act, flags=o.F_OBS | o.F_STATS)
-            else:
-                gpu.orca_step(with_obs=True, stats=True)
-                orc.orca_step(flags=o.F_OBS | o.F_STATS)
-            if s % 7 == 0 or s > 110:
-                H.assert_state_equal(gpu, orc, "%s N=%d step %d" % (scenario, N, s), obs=True)
-        gpu.close()
-    finally:
-        del os.environ["CA_FUSE_OBS"]
-
-
 def test_quad_freeze_rollout_equals_single_steps_and_oracle():
     """Episodes of different lengths end each where the serial loop would (ALAN:121-123), inside ONE launch."""
     A, N = 10, 12
