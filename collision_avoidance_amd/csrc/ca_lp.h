@@ -139,8 +139,10 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int ML, int ST, int I>
-__device__ __forceinline__ bool lp1_reg(const float4 (&L)[ML], int no, float radius, V2 opt, V2& result) {
+// (opt_fn() yields the optimisation point: a register pair, or -- for the workgroup shapes that run out of registers --
+// a read of the lane's LDS slot at each use, so that the value does not live in registers across the whole solve)
+template <int ML, int ST, int I, class OptFn>
+__device__ __forceinline__ bool lp1_reg(const float4 (&L)[ML], int no, float radius, OptFn opt_fn, V2& result) {
     const Line Li = unpack_line(L[I]);
     const float dp = dot(Li.point, Li.dir);
     const float disc = sqr(dp) + sqr(radius) - absSq(Li.point);
@@ -167,6 +169,7 @@ __device__ __forceinline__ bool lp1_reg(const float4 (&L)[ML], int no, float rad
         }
     });
     if (failed) return false;
+    const V2 opt = opt_fn();
     const float t = dot(Li.dir, opt - Li.point);
     if (t < tLeft) result = Li.point + tLeft * Li.dir;
     else if (t > tRight) result = Li.point + tRight * Li.dir;
@@ -176,10 +179,13 @@ __device__ __forceinline__ bool lp1_reg(const float4 (&L)[ML], int no, float rad
 
 // App. A.5 LP2 (dirOpt = false) over the register slots; returns the contract's line index of the
 // first infeasible line, or the line count when all lines are satisfied.
-template <int ML, int ST>
-__device__ __forceinline__ int lp2_reg(const float4 (&L)[ML], int no, int ncnt, float radius, V2 opt, V2& result) {
-    if (absSq(opt) > sqr(radius)) result = normalize(opt) * radius;
-    else result = opt;
+template <int ML, int ST, class OptFn>
+__device__ __forceinline__ int lp2_reg(const float4 (&L)[ML], int no, int ncnt, float radius, OptFn opt_fn, V2& result) {
+    {
+        const V2 opt = opt_fn();
+        if (absSq(opt) > sqr(radius)) result = normalize(opt) * radius;
+        else result = opt;
+    }
     int fail = no + ncnt;
     bool alive = true;
     static_for<ML>([&](auto ic) __attribute__((always_inline)) {
@@ -190,7 +196,7 @@ __device__ __forceinline__ int lp2_reg(const float4 (&L)[ML], int no, int ncnt, 
             const Line Li = unpack_line(L[i]);
             if (det(Li.dir, Li.point - result) > 0.0f) {
                 const V2 tmp = result;
-                if (!lp1_reg<ML, ST, i>(L, no, radius, opt, result)) {
+                if (!lp1_reg<ML, ST, i>(L, no, radius, opt_fn, result)) {
                     result = tmp;
                     fail = (i < ST) ? i : no + (i - ST);
                     alive = false;

@@ -90,6 +90,11 @@ __global__ __launch_bounds__(BS, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1) void s
     }
     s_px[tid] = pos.x; s_py[tid] = pos.y; s_vx[tid] = vel.x; s_vy[tid] = vel.y;
     reinterpret_cast<float*>(s_misc)[tid * 4 + 0] = pf32.x; reinterpret_cast<float*>(s_misc)[tid * 4 + 1] = pf32.y;
+    // workgroups of more than one wave carry more per-lane state: there the preferred velocity waits in the lane's LDS
+    // slot too (it is needed by every LP1 and by the epilogue; kept in registers it was spilled to scratch memory and
+    // reloaded 14 times inside LP2 -- tools/kernel_resources.py)
+    constexpr bool PARK_PREF = ST > 0 && BS > 64;
+    if constexpr (PARK_PREF) { reinterpret_cast<float*>(s_misc)[tid * 4 + 2] = pref.x; reinterpret_cast<float*>(s_misc)[tid * 4 + 3] = pref.y; }
     __syncthreads();
 
     CA_STAMP(1);
@@ -173,7 +178,11 @@ __global__ __launch_bounds__(BS, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1) void s
         // ---- 2-D linear program (App. A.5) on the register slots ----
         const int nl = no + ncnt;
         int fail = nl;
-        if (active) fail = lp2_reg<ML, ST>(L, no, ncnt, p.max_speed, pref, nv);
+        auto opt_fn = [&]() __attribute__((always_inline)) -> V2 {
+            if constexpr (PARK_PREF) return mk(reinterpret_cast<const float*>(s_misc)[tid * 4 + 2], reinterpret_cast<const float*>(s_misc)[tid * 4 + 3]);
+            else return pref;
+        };
+        if (active) fail = lp2_reg<ML, ST>(L, no, ncnt, p.max_speed, opt_fn, nv);
         CA_STAMP(6);
         CA_PRIO_POINT(5);
         // ---- LP3 for the lanes whose LP2 was infeasible: they copy their lines into a slot of the
@@ -263,7 +272,9 @@ __global__ __launch_bounds__(BS, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1) void s
     }
     if (active) {  // ---- integrate (App. A.1) ----
         vel = nv;
-        pos = mk(s_px[tid], s_py[tid]) + vel * p.time_step;  // own pre-step position: still in the staged arena
+        int tid_i = threadIdx.x;  // (behind an opaque move: the LDS address is derived here, not carried across the solve)
+        asm volatile("" : "+v"(tid_i));
+        pos = mk(s_px[tid_i], s_py[tid_i]) + vel * p.time_step;  // own pre-step position: still in the staged arena
     }
     CA_STAMP(7);
     CA_PRIO_POINT(6);
@@ -286,6 +297,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1) void s
     const int lbase = la << p.logP;
     const ObstDev* tab = p.obst + ((p.tab_off != nullptr && active) ? p.tab_off[a] : 0);
     pf32 = mk(reinterpret_cast<float*>(s_misc)[tid * 4 + 0], reinterpret_cast<float*>(s_misc)[tid * 4 + 1]);
+    if constexpr (PARK_PREF) pref = mk(reinterpret_cast<float*>(s_misc)[tid * 4 + 2], reinterpret_cast<float*>(s_misc)[tid * 4 + 3]);
 
     __syncthreads();  // every lane is done with the pre-step arena image
     s_px[tid] = pos.x; s_py[tid] = pos.y;
@@ -307,6 +319,7 @@ __global__ __launch_bounds__(BS, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1) void s
         bool scan_all = active && !(BS > 64 && p.neighbor_dist >= R + R + m2);  // arenas within one wave: the scan is cheaper
         if constexpr (BS > 64) if (active && !scan_all) {
             float far2 = 0.0f;
+            const int ncnt = (int)(p.counts[q] & 0xFFu);  // read again (this lane wrote it): not kept in a register across the solve
             int jn[KMAX];  // all list entries in flight at once
             static_for<KMAX>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;

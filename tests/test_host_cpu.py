@@ -110,3 +110,21 @@ def test_action_set_files(tmp_path):
     (tmp_path / "bad.act").write_text("[]")
     with pytest.raises(ValueError):
         alan.load_actions(str(tmp_path / "bad.act"))
+
+
+def test_no_hot_kernel_uses_scratch_memory():
+    """A register spill in a solve / observation kernel is HBM traffic (round 1: 19 MB per launch) and a dependent
+    memory round trip inside the LP: the compiler's own metadata must show 0 bytes of scratch for every hot kernel
+    (the LDS-line-table variant keeps LP3's projected lines in a private array by design).  Compiles the device
+    assembly once per source change (tools/kernel_resources.py, about a minute)."""
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    kr.ensure_asm()
+    rows = kr.parse()
+    assert any("step_kernel<10, 64, 4, true>" in r["name"] for r in rows) and any("quad_kernel<5, 64>" in r["name"] for r in rows)
+    bad = kr.spilling(rows)
+    assert not bad, [(r["name"], r["scratch"], r["vgpr_spill"]) for r in bad]
