@@ -302,7 +302,8 @@ void lp3(const std::vector<Line>& lines, int numObst, int begin, float radius, V
 }
 
 /* diagnostics: how often the infeasible path (LP3) is taken, and how many lines it re-solves */
-static uint64_t g_dbg[4] = {0, 0, 0, 0};
+static thread_local uint64_t g_dbg[4] = {0, 0, 0, 0};  /* per thread: a shared counter written for every agent-step
+                                                         * serialises the multi-core baseline on one cache line */
 
 /* App. A.3 + A.4 + the LP call sequence of A.5 */
 void compute_new_velocity(Arena& a, const std::vector<ObstVertex>& obst, int i, float timeStep) {
