@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--rollout-chunk", type=int, default=50,
                     help="--mode orca: steps per ca_rollout call (the ORCA-only policy rollout of env.py:570-573 / ALAN:106-123); "
                          "1 = one ca_orca_step call per step")
+    ap.add_argument("--arenas", type=int, default=None, help="diagnostic: override the workload's arena count (batch-size studies)")
     ap.add_argument("--as-rank", type=int, default=None,
                     help="rehearsal (tests): a single process plays rank R of a larger job -- arena offset R * arenas, action seed of rank R")
     return ap.parse_args()
@@ -210,7 +211,7 @@ def main():
     from collision_avoidance_amd import _lib
 
     w = scenarios.BENCH_CONFIGS[args.workload]
-    A, N = w["n_arenas"], w["n_agents"]
+    A, N = (args.arenas or w["n_arenas"]), w["n_agents"]
     p = scenarios.bench_params(N, w["neighbor_dist"], w["max_neighbors"])
     job_rank = rank if args.as_rank is None else args.as_rank
     arena_offset, _ = cad.weak_shard(A, job_rank)  # weak scaling: every GPU owns A arenas of the global range
@@ -226,7 +227,7 @@ def main():
     if args.steps % chunk or args.warmup % chunk:
         raise SystemExit("bench.py: --steps and --warmup must be multiples of --rollout-chunk (%d)" % chunk)
     lanes_per_agent = env.launch_info()["lanes_per_agent"]
-    steps_per_launch = chunk if lanes_per_agent == 4 else 1   # (one lane per agent: ca_rollout is a loop of launches)
+    steps_per_launch = chunk if (chunk > 1 and env.launch_info()["rollout_one_launch"]) else 1   # (else ca_rollout is a loop of launches)
 
     def one_step(i):  # the production call: one ca_step (neighbours -> ORCA solve -> observation) ...
         if full:

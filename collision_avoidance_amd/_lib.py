@@ -100,7 +100,7 @@ def load():
     L.ca_profile.argtypes = [vp, i32]
     L.ca_profile_read.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_float)]
     L.ca_launch_info.argtypes = [vp] + [C.POINTER(i32)] * 4
-    L.ca_solver_info.argtypes = [vp, C.POINTER(i32)]
+    L.ca_solver_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     for name in EXPORTS:
         if name != "ca_last_error":
             getattr(L, name).restype = C.c_int

@@ -62,6 +62,7 @@ struct ca_env {
     bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
     int ST = 0, KT = 16;  // solve-kernel variant: ST > 0 = register lines with ST obstacle slots; KT = KMAX
     bool quad = false;     // four lanes per agent (ca_quad.h): small batches / small arenas
+    bool quad_roll = false;  // ... for ca_rollout's one-launch-for-T-steps form (pays a little longer than for single steps)
     int BSq = 64, grid_q = 1;
     size_t lds_q = 0;
     size_t lds = 0;
@@ -265,7 +266,7 @@ static hipError_t set_quad_lds_attr(int BS, size_t lds) {
     return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 static hipError_t launch_step(ca_env* e, const StepArgs& a) {
-    if (e->quad) return e->KT == 5 ? launch_quad_k<5>(e, a) : launch_quad_k<10>(e, a);
+    if (e->quad || (a.T > 1 && e->quad_roll)) return e->KT == 5 ? launch_quad_k<5>(e, a) : launch_quad_k<10>(e, a);
     if (e->ST > 0) return e->KT == 5 ? launch_step_k<5, 4>(e, a) : launch_step_k<10, 4>(e, a);
     if (e->K <= 5) return launch_step_k<5, 0>(e, a);
     if (e->K <= 10) return launch_step_k<10, 0>(e, a);
@@ -480,12 +481,14 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->ST = (allow && e->K <= 10 && e->S <= 4) ? 4 : 0;
     }
     e->lds = step_lds_bytes(e->BS, e->K, e->S, e->ST, e->KT);
-    {   // four lanes per agent (ca_quad.h) where one lane per agent would leave the chip short of waves: fewer than two
-        // waves per SIMD (1024 SIMDs) and an arena that fits a workgroup at four lanes per agent
+    {   // four lanes per agent (ca_quad.h) where one lane per agent would leave SIMDs without a wave: fewer than 1024
+        // waves.  Measured crossover (profiles/r03_d_lane_vs_quad_by_batch_size.txt): 16-agent arenas -- quad ahead up to
+        // 2048 arenas (512 lane-waves), behind from 4096 (1024); 64-agent arenas -- ahead up to 512 arenas, level at 1024.
         const char* v = getenv("CA_QUAD");  // 0 / 1 forces the choice (tests run the parity suite both ways)
         const bool fits = e->ST > 0 && 4 * P <= 512;  // (a 1024-lane workgroup caps the kernel at 128 VGPRs: it spills)
         const long lane_waves = (long)e->grid * (e->BS / 64);
-        e->quad = fits && (v ? v[0] == '1' : lane_waves < 2048);
+        e->quad = fits && (v ? v[0] == '1' : lane_waves < 1024);
+        e->quad_roll = fits && (v ? v[0] == '1' : lane_waves <= 1024);  // T steps per launch: ahead at 1024 lane-waves too
         e->BSq = 4 * P > 64 ? 4 * P : 64;
         const int apbq = (e->BSq / 4) / P;
         e->grid_q = (cfg->n_arenas + apbq - 1) / apbq;
@@ -531,7 +534,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         else if (e->K <= 10) r = set_lds_attr_k<10, 0>(e->BS, e->lds);
         else r = set_lds_attr_k<16, 0>(e->BS, e->lds);
     }
-    if (r == hipSuccess && e->quad && e->lds_q > 48 * 1024)
+    if (r == hipSuccess && e->quad_roll && e->lds_q > 48 * 1024)
         r = e->KT == 5 ? set_quad_lds_attr<5>(e->BSq, e->lds_q) : set_quad_lds_attr<10>(e->BSq, e->lds_q);
     if (r == hipSuccess) {
         const int obs_bs = obs_block_threads(cfg->n_agents);
@@ -1114,7 +1117,7 @@ int ca_observe(ca_env* e) {
 int ca_rollout(ca_env* e, int32_t steps, uint32_t flags) {
     if (!e || steps < 0) return fail(e, CA_EINVAL, "ca_rollout: bad argument");
     HIPCHK(e, hipSetDevice(e->device));
-    if (e->quad && !(flags & CA_F_OBS) && steps > 0) {
+    if (e->quad_roll && !(flags & CA_F_OBS) && steps > 1) {
         // ONE launch: the workgroup that owns an arena keeps it in registers / LDS for all `steps` steps (ca_quad.h)
         if (e->prof_period > 1) e->profiling = (e->steps_done % (uint64_t)e->prof_period) == 0;
         StepArgs a;
@@ -1258,9 +1261,10 @@ int ca_launch_info(ca_env* e, int32_t* block, int32_t* grid, int32_t* lds_bytes,
     return CA_OK;
 }
 
-int ca_solver_info(ca_env* e, int32_t* lanes_per_agent) {
+int ca_solver_info(ca_env* e, int32_t* lanes_per_agent, int32_t* rollout_one_launch) {
     if (!e) return CA_EINVAL;
     if (lanes_per_agent) *lanes_per_agent = e->quad ? 4 : 1;
+    if (rollout_one_launch) *rollout_one_launch = e->quad_roll ? 1 : 0;
     return CA_OK;
 }
 

@@ -215,10 +215,10 @@ class VecCollisionAvoidanceEnv:
     def launch_info(self):
         v = [C.c_int32() for _ in range(4)]
         self._call("ca_launch_info", self.h, *[C.byref(x) for x in v])
-        lanes = C.c_int32()
-        self._call("ca_solver_info", self.h, C.byref(lanes))
+        lanes, roll = C.c_int32(), C.c_int32()
+        self._call("ca_solver_info", self.h, C.byref(lanes), C.byref(roll))
         return dict(block=v[0].value, grid=v[1].value, lds_bytes=v[2].value, obs_grid=v[3].value,
-                    lanes_per_agent=lanes.value)
+                    lanes_per_agent=lanes.value, rollout_one_launch=roll.value)
 
     # ---- the environment API ----------------------------------------------------------------------
     def _on_device(self, t, dtype):

@@ -111,6 +111,33 @@ def test_quad_freeze_rollout_equals_single_steps_and_oracle():
         e.close()
 
 
+def test_lane_steps_and_quad_rollouts_share_one_handle():
+    """At exactly one lane-wave per SIMD the handle steps with one lane per agent and rolls out with four (the two
+    kernels work on the same state arrays): alternate them and compare with the oracle."""
+    del os.environ["CA_QUAD"]
+    try:
+        A, N = 4096, 16
+        p = scenarios.bench_params(N, 1.5, 5)
+        gpu = H.make_gpu(A, N, "crowd", p, seed=13)
+        info = gpu.launch_info()
+        assert info["lanes_per_agent"] == 1 and info["rollout_one_launch"] == 1, info
+        orc = H.make_oracle(A, N, "crowd", p, seed=13)
+        rng = np.random.RandomState(13)
+        for block in range(3):
+            for s in range(2):
+                act = rng.uniform(-0.7, 0.7, (A, N)).astype(np.float32)
+                gpu.step(act, stats=True)
+                orc.step_mt(act, flags=o.F_OBS | o.F_STATS, n_threads=8)
+            H.assert_state_equal(gpu, orc, "after steps, block %d" % block, obs=True, reward=True)
+            gpu.rollout(6 + block, stats=True)
+            orc.rollout(6 + block, flags=o.F_STATS, n_threads=8)
+            H.assert_state_equal(gpu, orc, "after rollout, block %d" % block)
+        H.assert_stats_equal(gpu, orc, "mixed")
+        gpu.close()
+    finally:
+        os.environ["CA_QUAD"] = "1"
+
+
 def test_quad_is_the_default_for_small_batches_only():
     del os.environ["CA_QUAD"]
     small = H.make_gpu(64, 16, "crowd", scenarios.bench_params(16, 1.5, 5))
