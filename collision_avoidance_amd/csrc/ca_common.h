@@ -172,7 +172,7 @@ __device__ __forceinline__ ObstDev load_obst(const ObstDev* __restrict__ t, int 
         __builtin_amdgcn_sched_barrier(0);                                               \
         const unsigned long long _t = CA_STAMP_CLOCK();                                  \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                              \
-        if ((threadIdx.x & 63) == 0 && p.dbg)                                            \
+        if ((threadIdx.x & 63) == 0 && threadIdx.x < BS && p.dbg)                        \
             p.dbg[((size_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6)) * 16 + (k)] = _t; \
         __builtin_amdgcn_sched_barrier(0);                                               \
     } while (0)

@@ -61,6 +61,7 @@ struct ca_env {
     int BSn = 64, grid_n = 1;  // the neighbour kernel's own workgroup size
     bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
     int ST = 0, KT = 16;  // solve-kernel variant: ST > 0 = register lines with ST obstacle slots; KT = KMAX
+    bool help = false;     // large arenas: helper lanes in the uniform-grid neighbour scan (ca_nbr.h, HELP = 2)
     bool quad = false;     // four lanes per agent (ca_quad.h): small batches / small arenas
     bool quad_roll = false;  // ... for ca_rollout's one-launch-for-T-steps form (pays a little longer than for single steps)
     int BSq = 64, grid_q = 1;
@@ -229,6 +230,13 @@ static hipError_t launch_step_kf(ca_env* e, const StepArgs& a) {
     if (!FUSE) launch_nbr_k<KMAX, (ST > 0 ? ST : SMAX)>(e, a);  // neighbour search as a launch of its own (diagnostic: CA_FUSE_NBR=0)
     const dim3 grid(e->grid), block(e->BS);
     ProfScope ps(e, KIND_STEP);
+    if constexpr (FUSE && ST > 0) {
+        if (e->help) {  // twice the lanes: the upper half helps in the neighbour scan of its arena and ends (ca_nbr.h)
+            if (e->BS == 256) hipLaunchKernelGGL((step_kernel<KMAX, 256, ST, true, 2>), grid, dim3(512), e->lds, e->stream, a);
+            else hipLaunchKernelGGL((step_kernel<KMAX, 512, ST, true, 2>), grid, dim3(1024), e->lds, e->stream, a);
+            return hipGetLastError();
+        }
+    }
     switch (e->BS) {  // (neighbour search +) lines + LP + integration + reward/done
         case 64: hipLaunchKernelGGL((step_kernel<KMAX, 64, ST, FUSE>), grid, block, e->lds, e->stream, a); break;
         case 128: hipLaunchKernelGGL((step_kernel<KMAX, 128, ST, FUSE>), grid, block, e->lds, e->stream, a); break;
@@ -481,6 +489,11 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->ST = (allow && e->K <= 10 && e->S <= 4) ? 4 : 0;
     }
     e->lds = step_lds_bytes(e->BS, e->K, e->S, e->ST, e->KT);
+    {   // helper lanes for the uniform-grid neighbour scan: arenas of 192 .. 512 agents on the register-line kernel
+        const char* v = getenv("CA_NBR_HELP");  // diagnostic switch: 0 = none
+        e->help = !(v && v[0] == '0') && e->fuse_nbr && e->ST > 0 && (e->BS == 256 || e->BS == 512) &&
+                  cfg->n_agents >= 192 && e->K > 0;
+    }
     {   // four lanes per agent (ca_quad.h) where one lane per agent would leave SIMDs without a wave: fewer than 1024
         // waves.  Measured crossover (profiles/r03_d_lane_vs_quad_by_batch_size.txt): 16-agent arenas -- quad ahead up to
         // 2048 arenas (512 lane-waves), behind from 4096 (1024); 64-agent arenas -- ahead up to 512 arenas, level at 1024.
@@ -495,7 +508,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->lds_q = quad_lds_bytes(e->BSq, e->KT);
     }
     // + the statically allocated LDS of the fused neighbour search: positions, and for >= 256 lanes the grid tables
-    const size_t lds_static = (size_t)e->BS * 8 + (e->BS >= 256 ? (size_t)e->BS * 2 + 16 + 1024 + 1028 : 0) + 64;
+    const size_t lds_static = (e->help ? (size_t)e->KT * e->BS * 8 : 0) + (size_t)e->BS * 8 + (e->BS >= 1024 ? (size_t)e->BS * 2 + 16 + 1024 + 1028 : (e->BS >= 256 ? (size_t)e->BS * 2 + 16 + 4096 + 4100 : 0)) + 64;
     if (e->lds + lds_static > 160 * 1024) {
         fail(nullptr, CA_ERANGE, "ca_create: the solve kernel would need %zu B of LDS (> 160 KiB) for n_agents=%d, "
              "max_neighbors=%d, max_obst_neighbors=%d: arenas above 256 agents need max_neighbors <= 10 and "
@@ -528,6 +541,13 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     if (r == hipSuccess) r = dalloc(e, &e->dbg, (size_t)std::max(std::max(e->grid * (e->BS / 64), e->grid_n * (e->BSn / 64)), e->grid_q * (e->BSq / 64)) * 16);
     if (r == hipSuccess) r = dalloc(e, &e->dbg_obs, (size_t)cfg->n_arenas * ((cfg->n_agents + 15) / 16 + 16) * 4 * 16);
 #endif
+    if (r == hipSuccess && e->help && e->lds > 48 * 1024) {
+        const void* f = e->KT == 5 ? (e->BS == 256 ? reinterpret_cast<const void*>(&step_kernel<5, 256, 4, true, 2>)
+                                                   : reinterpret_cast<const void*>(&step_kernel<5, 512, 4, true, 2>))
+                                   : (e->BS == 256 ? reinterpret_cast<const void*>(&step_kernel<10, 256, 4, true, 2>)
+                                                   : reinterpret_cast<const void*>(&step_kernel<10, 512, 4, true, 2>));
+        r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds);
+    }
     if (r == hipSuccess && e->lds > 48 * 1024) {
         if (e->ST > 0) r = e->KT == 5 ? set_lds_attr_k<5, 4>(e->BS, e->lds) : set_lds_attr_k<10, 4>(e->BS, e->lds);
         else if (e->K <= 5) r = set_lds_attr_k<5, 0>(e->BS, e->lds);

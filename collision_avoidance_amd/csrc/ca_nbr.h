@@ -50,8 +50,13 @@ __device__ __forceinline__ void sorted_insert(double (&key)[MAXN], double x) {
 // its 16 B x (K+S) line table per lane.
 // ============================================================================================
 // SM: capacity of the register list of obstacle neighbours (S <= SM): 4 for the register-line solve, SMAX for the LDS table
-template <int KMAX, int BS, int SM>
-__device__ __forceinline__ void nbr_body(const StepArgs& p) {
+// HELP = 2: the workgroup is launched with 2 BS lanes; lanes BS .. 2 BS - 1 are HELPERS of agents 0 .. BS - 1 for the
+// uniform-grid scan only (large arenas: the scan is the longest dependent chain of the step and a 512-agent arena is
+// just 8 waves on its CU): main lane and helper take alternate candidates of every cell row, each keeping its K nearest,
+// the helper hands its list over through LDS and ends; the main lane inserts it into its own (keys are totally ordered:
+// the K smallest of the union are the serial scan's list).  Returns true for a helper lane (the caller returns too).
+template <int KMAX, int BS, int SM, int HELP = 1>
+__device__ __forceinline__ bool nbr_body(const StepArgs& p) {
 #ifndef CA_NBR_NO_VGPR_PAD
     // Claim 128 VGPRs (the kernel needs 56): at most 4 waves then fit on a SIMD, so a launch that brings one
     // wave per SIMD slot (4096 x 64 lanes on 256 CUs) is spread evenly.  Without it the dispatcher puts
@@ -60,7 +65,9 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
 #endif
     __shared__ float s_px[BS];
     __shared__ float s_py[BS];
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
+    const bool helper = HELP > 1 && tid0 >= BS;   // (whole waves: BS is a multiple of 64)
+    const int tid = helper ? tid0 - BS : tid0;    // the agent slot this lane works for
     const int P = p.P;
     const int la = tid >> p.logP;
     const int i = tid & (P - 1);
@@ -72,9 +79,10 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
     const int lbase = la << p.logP;
     CA_STAMP(12);
     V2 pos = mk(0.0f, 0.0f);
-    if (active) pos = mk(p.pos_x[q], p.pos_y[q]);
-    s_px[tid] = pos.x; s_py[tid] = pos.y;
+    if (active && !helper) pos = mk(p.pos_x[q], p.pos_y[q]);
+    if (!helper) { s_px[tid] = pos.x; s_py[tid] = pos.y; }
     __syncthreads();
+    if (helper) pos = mk(s_px[tid], s_py[tid]);
 
     const float INF = __int_as_float(0x7f800000);
     // ---- obstacle neighbours (App. A.2): brute force over the edge table ----
@@ -99,7 +107,8 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
                 }
             }
         };
-        if (p.tab_off == nullptr) {  // one table for every arena: uniform loop, scalar loads of the edge records
+        if (helper) {                // (helpers work in the agent scan only)
+        } else if (p.tab_off == nullptr) {  // one table for every arena: uniform loop, scalar loads of the edge records
             for (int e = 0; e < p.n_obst; ++e) visit(p.obst[e], e, active);
         } else {                     // a table per arena (several arenas may share this wave): ids are local to it
             const int t0 = active ? p.tab_off[a] : 0, ne = active ? p.tab_off[a + 1] - t0 : 0;
@@ -122,62 +131,71 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
     if constexpr (BS >= 256) {
         // Large arenas (one arena per workgroup, >= 192 agents): a uniform grid with cells at least neighbor_dist
         // wide, rebuilt in LDS every step (counting sort of the agent indices by cell), so that an agent scans
-        // the 3 x 3 cells around it -- three contiguous runs of the sorted list -- instead of the whole arena.
+        // the block of cells around it -- one contiguous run of the sorted list per cell row -- instead of the whole arena.
         // The cells are visited in no particular index order, so a candidate enters on `distance <= current
         // K-th distance` and the 64-bit (distance, index) keys settle ties; the list is the same K smallest
         // keys within neighbor_dist that the index-order scan keeps.
         if (P == BS && N >= 192 && K > 0) {
+            constexpr int GMAX = BS >= 1024 ? 16 : 32;  // at most GMAX x GMAX cells (the 1024-lane shape has no LDS to spare)
             __shared__ unsigned s_box[4];          // ordered-uint images of min x, min y, max x, max y
-            __shared__ int s_ccnt[256];            // agents per cell
-            __shared__ int s_cstart[257];          // first position of a cell in s_sorted
+            __shared__ int s_ccnt[GMAX * GMAX];    // agents per cell
+            __shared__ int s_cstart[GMAX * GMAX + 1];  // first position of a cell in s_sorted
             __shared__ unsigned short s_sorted[BS];
             auto ord = [](float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
             auto unord = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); };
-            if (tid < 2) s_box[tid] = 0xFFFFFFFFu;
-            if (tid >= 2 && tid < 4) s_box[tid] = 0u;
-            if (tid < 256) s_ccnt[tid] = 0;
+            if (tid0 < 2) s_box[tid0] = 0xFFFFFFFFu;
+            if (tid0 >= 2 && tid0 < 4) s_box[tid0] = 0u;
+            for (int cidx = tid0; cidx < GMAX * GMAX; cidx += BS * HELP) s_ccnt[cidx] = 0;
             __syncthreads();
-            const bool in_arena = (a < p.a1) && (i < N);  // frozen arenas skip the scan but keep the barriers
+            const bool in_arena = (a < p.a1) && (i < N) && !helper;  // frozen arenas skip the scan but keep the barriers
             if (in_arena) {
                 atomicMin(&s_box[0], ord(pos.x)); atomicMin(&s_box[1], ord(pos.y));
                 atomicMax(&s_box[2], ord(pos.x)); atomicMax(&s_box[3], ord(pos.y));
             }
             __syncthreads();
+            // Cells half a neighbour range wide (the 5 x 5 block around an agent's cell covers its range with 156 / 225 of
+            // the area of 3 x 3 cells a full range wide: a third fewer candidates), or wider when the arena is so large that
+            // 32 x 32 of them would not cover it; RC = cells to either side that can hold a neighbour (1 or 2).
             const float x0 = unord(s_box[0]), y0 = unord(s_box[1]);
             const float ex = unord(s_box[2]) - x0, ey = unord(s_box[3]) - y0;
-            const float cs = fmaxf(p.neighbor_dist, fmaxf(ex, ey) * (1.0f / 15.5f));  // at most 16 x 16 cells
+            const float cs = fmaxf((GMAX >= 32 ? 0.5f : 1.0f) * p.neighbor_dist, fmaxf(ex, ey) * (1.0f / (GMAX - 0.5f)));
+            const int RC = (cs >= p.neighbor_dist) ? 1 : 2;
             const float ics = 1.0f / cs;
-            const int Gx = min(16, (int)(ex * ics) + 1), Gy = min(16, (int)(ey * ics) + 1);
+            const int Gx = min(GMAX, (int)(ex * ics) + 1), Gy = min(GMAX, (int)(ey * ics) + 1);
             const int cx = min(Gx - 1, max(0, (int)((pos.x - x0) * ics))), cy = min(Gy - 1, max(0, (int)((pos.y - y0) * ics)));
             int rank = 0;
             if (in_arena) rank = atomicAdd(&s_ccnt[cy * Gx + cx], 1);
             __syncthreads();
-            if (tid < 64) {  // exclusive prefix sum over the (<= 256) cells: four cells per lane of the first wave
-                const int c0 = s_ccnt[4 * tid], c1 = s_ccnt[4 * tid + 1], c2 = s_ccnt[4 * tid + 2], c3 = s_ccnt[4 * tid + 3];
-                int incl = c0 + c1 + c2 + c3;
+            if (tid0 < 64) {  // exclusive prefix sum over the cells: GMAX^2 / 64 cells per lane of the first wave
+                constexpr int CPL = GMAX * GMAX / 64;
+                int cnt[CPL];
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) { cnt[k] = s_ccnt[CPL * tid0 + k]; sum += cnt[k]; }
+                int incl = sum;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
                     const int t = __shfl_up(incl, off);
-                    if (tid >= off) incl += t;
+                    if (tid0 >= off) incl += t;
                 }
-                const int b = incl - (c0 + c1 + c2 + c3);
-                s_cstart[4 * tid] = b; s_cstart[4 * tid + 1] = b + c0; s_cstart[4 * tid + 2] = b + c0 + c1;
-                s_cstart[4 * tid + 3] = b + c0 + c1 + c2;
-                if (tid == 63) s_cstart[256] = incl;
+                int b = incl - sum;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) { s_cstart[CPL * tid0 + k] = b; b += cnt[k]; }
+                if (tid0 == 63) s_cstart[GMAX * GMAX] = incl;
             }
             __syncthreads();
             if (in_arena) s_sorted[s_cstart[cy * Gx + cx] + rank] = (unsigned short)i;
             __syncthreads();
             const float rangeSq0 = sqr(p.neighbor_dist);
             float rangeK = rangeSq0;  // distance of the current K-th entry once the list is full
-            for (int ry = -1; ry <= 1; ++ry) {
+            for (int ry = -RC; ry <= RC; ++ry) {
                 const int row = cy + ry;
                 int lo = 0, hi = 0;
                 if (active && row >= 0 && row < Gy) {
-                    lo = s_cstart[row * Gx + max(cx - 1, 0)];
-                    hi = s_cstart[row * Gx + min(cx + 1, Gx - 1) + 1];
+                    lo = s_cstart[row * Gx + max(cx - RC, 0)];
+                    hi = s_cstart[row * Gx + min(cx + RC, Gx - 1) + 1];
                 }
-                for (int t = lo; t < hi; ++t) {
+                for (int t = lo + (helper ? 1 : 0); t < hi; t += HELP) {
                     const int j = s_sorted[t];
                     const float dsq = absSq(pos - mk(s_px[j], s_py[j]));
                     if (j != i && dsq < rangeSq0 && dsq <= rangeK) {
@@ -186,6 +204,21 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
                         if (ncnt == K) rangeK = key_dist(nkey[KMAX - 1]);
                     }
                 }
+            }
+            if constexpr (HELP > 1) {  // the helper's list -> LDS -> the main lane's list
+                __shared__ double s_hkey[KMAX][BS];
+                if (helper) {
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) s_hkey[k][tid] = nkey[k];
+                }
+                __syncthreads();
+                if (helper) return true;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k >= kofs) sorted_insert<KMAX>(nkey, s_hkey[k][tid]);  // (an empty slot is the largest key: no effect)
+                ncnt = 0;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) ncnt += (k >= kofs && key_index(nkey[k]) >= 0) ? 1 : 0;
             }
             scanned = true;
         }
@@ -263,6 +296,7 @@ __device__ __forceinline__ void nbr_body(const StepArgs& p) {
             if (k >= sofs) p.obst_idx[((size_t)a * S + (k - sofs)) * N + i] = (unsigned short)key_index(okey[k]);
     }
     CA_STAMP(15);
+    return false;
 }
 
 template <int KMAX, int BS, int SM>

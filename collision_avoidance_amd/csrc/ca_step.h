@@ -31,14 +31,15 @@ typedef const __attribute__((address_space(4))) StepCold ColdK;  // the cold blo
 #ifndef CA_LB512
 #define CA_LB512 4   // waves per SIMD the 512-lane register-line kernel is built for (diagnostic: 2 = 256 VGPRs)
 #endif
-template <int KMAX, int BS, int ST, bool FUSE>
-__global__ __launch_bounds__(BS, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1) void step_kernel(const StepArgs p) {
+// HELP = 2: launched with 2 BS lanes, the upper half helps in the neighbour scan and ends (ca_nbr.h)
+template <int KMAX, int BS, int ST, bool FUSE, int HELP = 1>
+__global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1) void step_kernel(const StepArgs p) {
     extern __shared__ float4 smem4[];
     CA_PRIO_START();
     // FUSE: the neighbour search runs at the head of this kernel instead of in a launch of its own (one
     // drain/fill less per step, and its dispatch skew overlaps useful work).  A lane later reads back only the
     // lists of its own agent, which it wrote itself; the search's LDS arrays are not used again.
-    if constexpr (FUSE) nbr_body<KMAX, BS, (ST > 0 ? ST : SMAX)>(p);
+    if constexpr (FUSE) { if (nbr_body<KMAX, BS, (ST > 0 ? ST : SMAX), HELP>(p)) return; }
     constexpr int ML = ST + KMAX;  // register slots (ST > 0)
     const int tid = threadIdx.x;
     const int P = p.P;
