@@ -90,6 +90,12 @@ CASES = [
     ("grid_circle", 2, 256, "circle", dict(), 40, 10),
     ("grid_incoming", 2, 226, "incoming", dict(), 60, 20),
     ("grid_smallrange", 2, 400, "crowd", dict(neighbor_dist=1.5, max_neighbors=5), 40, 10),
+    # ... with helper lanes in the scan (192-512 agents): list shorter than the register array (K = 7 of 10, 3 of 5),
+    # an arena that fills the 512-lane shape exactly, one just above the threshold
+    ("grid_k7", 2, 300, "crowd", dict(neighbor_dist=4.0, max_neighbors=7), 30, 10),
+    ("grid_k3", 3, 200, "crowd", dict(neighbor_dist=2.0, max_neighbors=3), 30, 10),
+    ("grid_512", 1, 512, "crowd", dict(), 20, 10),
+    ("grid_192", 3, 192, "circle", dict(), 30, 10),
     # SURVEY 8d bench variants: rejection-sampled non-overlapping starts
     ("separated", 12, 64, "crowd_separated", dict(), 150, 50),
 ]
@@ -500,6 +506,29 @@ def test_world_without_obstacles_and_ragged_edges():
         g.orca_step(with_obs=True, stats=True); e.orca_step(flags=o.F_OBS | o.F_STATS)
     H.assert_state_equal(g, e, "single agents", obs=True)
     H.assert_stats_equal(g, e, "single agents")
+    g.close()
+
+
+def test_frozen_large_arenas_stay_untouched():
+    """CA_F_FREEZE with the helper-lane neighbour scan (200 agents per arena): an arena whose arena_done flag is set
+    is left exactly as it is -- state, lists, counters -- while its neighbours in the batch advance (ALAN:121-123)."""
+    from collision_avoidance_amd import _lib
+    A, N = 3, 200
+    p = H.scenario_params("crowd", N)
+    g = H.make_gpu(A, N, "crowd", p, seed=6)
+    e = H.make_oracle(A, N, "crowd", p, seed=6)
+    for env, step in ((g, lambda: g.orca_step(stats=True, freeze=True)), (e, lambda: e.orca_step(flags=o.F_STATS | o.F_FREEZE))):
+        step(); step()
+    H.assert_state_equal(g, e, "before freezing")
+    done = np.array([0, 1, 0], np.int32)
+    g.set(_lib.FLD_ARENA_DONE, done); e.set(o.FLD_ARENA_DONE, done)
+    before = g.get(_lib.FLD_POS_X)[1].copy()
+    for s in range(6):
+        g.orca_step(stats=True, freeze=True); e.orca_step(flags=o.F_STATS | o.F_FREEZE)
+    H.assert_state_equal(g, e, "one arena frozen")
+    H.assert_stats_equal(g, e, "one arena frozen")
+    np.testing.assert_array_equal(g.get(_lib.FLD_POS_X)[1], before)
+    assert not np.array_equal(g.get(_lib.FLD_POS_X)[0], before)
     g.close()
 
 

@@ -83,6 +83,57 @@ def test_quad_step_with_actions_obs_and_autoreset(N, K):
     gpu.close()
 
 
+def test_quad_with_a_world_per_arena():
+    """Per-arena obstacle tables (ca_set_obstacles_per_arena: ids local to each arena's table) under the quad kernel: a
+    different triangle or wedge in every arena (at most four edges in range), several arenas per wave."""
+    A, N = 22, 6
+    p = H.scenario_params("crowd", N, neighbor_dist=3.0, max_neighbors=5)
+    rng = np.random.RandomState(3)
+    worlds = []
+    for a in range(A):
+        c = rng.uniform(2.0, 4.0, 2)
+        if a % 3 == 2:
+            worlds.append([])                                            # an arena without any obstacle
+        elif a % 3 == 1:
+            worlds.append([[(c[0], c[1]), (c[0] + 1.0, c[1] + 0.2), (c[0] + 0.3, c[1] + 1.1)]])          # counter-clockwise triangle
+        else:
+            worlds.append([[(c[0], c[1]), (c[0] + 0.2, c[1] + 1.0), (c[0] + 1.2, c[1] + 0.9), (c[0] + 1.0, c[1] - 0.1)][::-1]])
+    g = H.make_gpu(A, N, "crowd", p, seed=8, polys=dict(per_arena=worlds), max_obst_neighbors=4)
+    assert _is_quad(g)
+    e = H.make_oracle(A, N, "crowd", p, seed=8, polys=dict(per_arena=worlds), max_obst_neighbors=4)
+    rng = np.random.RandomState(8)
+    for s in range(150):
+        if s % 3 == 0:
+            g.rollout(2, stats=True); e.rollout(2, flags=o.F_STATS)
+        else:
+            act = rng.uniform(-0.9, 0.9, (A, N)).astype(np.float32)
+            g.step(act, stats=True); e.step(act, flags=o.F_OBS | o.F_STATS)
+        if s % 25 == 0 or s > 140:
+            H.assert_state_equal(g, e, "per-arena worlds, step %d" % s, obs=(s % 3 != 0))
+    H.assert_stats_equal(g, e, "per-arena worlds")
+    assert g.stats()["obst_collisions"] > 0 or g.get(5).any()       # the obstacles were in somebody's way
+    g.close()
+
+
+@pytest.mark.parametrize("done_mode", [0, 1, 2])
+def test_quad_done_modes(done_mode):
+    """The three done tests (env.py:352-365 x-threshold, ALAN:547-566 goal, the synthetic re-goal) in the quad kernel's
+    T-steps-per-launch loop, with the step cap and auto-reset."""
+    A, N = 9, 14
+    p = scenarios.bench_params(N, 2.5, 5)
+    p.update(done_mode=done_mode, max_step=90, done_x_thresh=3.0)
+    g = H.make_gpu(A, N, "crowd", p, seed=4)
+    assert _is_quad(g)
+    e = H.make_oracle(A, N, "crowd", p, seed=4)
+    for chunk in (1, 30, 45, 100, 13):
+        g.rollout(chunk, stats=True, autoreset=True)
+        e.rollout(chunk, flags=o.F_STATS | o.F_AUTORESET)
+        H.assert_state_equal(g, e, "done_mode %d after a launch of %d" % (done_mode, chunk))
+    H.assert_stats_equal(g, e, "done modes")
+    assert g.stats()["episodes"] >= A
+    g.close()
+
+
 def test_quad_freeze_rollout_equals_single_steps_and_oracle():
     """Episodes of different lengths end each where the serial loop would (ALAN:121-123), inside ONE launch."""
     A, N = 10, 12
