@@ -9,8 +9,14 @@ SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("ca_env.hip", "ca_kernels.h"
                                                     "ca_alan.h", "ca_obs.h", "ca_math.h")] + \
           [os.path.join(os.path.dirname(_HERE), "include", "ca_env.h")]
 # -ffp-contract=off: no FMA contraction -- the numerics contract shared with the parity oracle.
+# -fno-slp-vectorize: keeps the compiler from packing adjacent scalar fp32 adds / multiplies into v_pk_add_f32 /
+#   v_pk_mul_f32.  On gfx950 a packed instruction issues every ~4.3 cycles against ~2.7 for v_add_f32 / v_mul_f32
+#   (profiles/r02_valu_issue_rates_microbench.txt), so two scalar operations cost 5.4 cycles and the packed one 4.3 PLUS
+#   the v_mov shuffles that line the operands up in register pairs (18 % of the observation kernel's pair loop): these
+#   issue-bound kernels run 10 % faster without it (obs_kernel 80.5 -> 69.6 us, step_kernel 72.0 -> 68.9 us at C3; same
+#   IEEE operations, bit-identical results; profiles/r03_e_no_slp_packing.txt).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-Wno-unused-value"]
+               "-fno-slp-vectorize", "-Wno-unused-value"]
 
 
 def source_sha():
@@ -18,6 +24,7 @@ def source_sha():
     that of the sources the loaded library was built from."""
     import hashlib
     h = hashlib.sha256()
+    h.update(" ".join(HIPCC_FLAGS).encode())   # the compiler flags are part of what a profile was taken from
     for f in sorted(SOURCES):
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode() + b"\0" + fh.read())
