@@ -30,7 +30,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 VALU_PEAK_LANE_OPS = 256 * 128 * 2.4e9  # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz: the rate behind the 157 TFLOP/s fp32 peak,
 #                                         which only packed FMAs reach (profiles/r02_valu_issue_rates_microbench.txt)
 # what a SIMD really issues for the instruction mix of these kernels: ~4.2 cycles for most vector instructions, ~2.7 for
-# plain add / mul / and / mov, 8.3 for rcp / sqrt (same file); 4.0 is the mix average used for the issue-bound estimate
+# plain add / mul / and / mov, 8.3 for rcp / sqrt (same file); the issue-bound estimate prices each instruction class
+# from the class counters of the committed profile (4.0 per instruction if a profile has none)
 ISSUE_CYCLES_PER_VALU = 4.0
 N_SIMDS, CLOCK_HZ = 1024, 2.4e9
 # algorithmic bytes per agent-step
@@ -304,15 +305,35 @@ def main():
                 cnt = {k: float(kk[k]["SQ_INSTS_VALU"]) for k in kms_of}
                 lane_ops = 64.0 * sum(cnt.values())
                 tsum = sum(kms_of.values()) * 1e-3
-                bound_ms = {k: cnt[k] * ISSUE_CYCLES_PER_VALU / N_SIMDS / CLOCK_HZ * 1e3 for k in kms_of}
+
+                def issue_cycles(c, cheap_other):
+                    """Vector-issue cycles of one launch from the instruction-class counters and the measured issue
+                    cost of each class on gfx950 (profiles/r02_valu_issue_rates_microbench.txt): v_add / v_mul_f32 2.7,
+                    v_fma_f32 3.9, transcendental 8.3, conversions / 64-bit integer 4.2; 32-bit integer and the rest
+                    (compares, selects, moves, min / max, DPP ...) between 2.7 (and, add, mov) and 4.2 (the others):
+                    `cheap_other` picks the end of that range."""
+                    known = ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+                             "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT")
+                    if not all(x in c for x in known):
+                        return float(c["SQ_INSTS_VALU"]) * ISSUE_CYCLES_PER_VALU
+                    other = float(c["SQ_INSTS_VALU"]) - sum(float(c[x]) for x in known)
+                    flex = 2.7 if cheap_other else 4.2
+                    return ((float(c["SQ_INSTS_VALU_ADD_F32"]) + float(c["SQ_INSTS_VALU_MUL_F32"])) * 2.7 +
+                            float(c["SQ_INSTS_VALU_FMA_F32"]) * 3.9 + float(c["SQ_INSTS_VALU_TRANS_F32"]) * 8.3 +
+                            (float(c["SQ_INSTS_VALU_INT64"]) + float(c["SQ_INSTS_VALU_CVT"])) * 4.2 +
+                            (float(c["SQ_INSTS_VALU_INT32"]) + max(0.0, other)) * flex)
+                bound_hi = {k: issue_cycles(kk[k], False) / N_SIMDS / CLOCK_HZ * 1e3 for k in kms_of}
+                bound_lo = {k: issue_cycles(kk[k], True) / N_SIMDS / CLOCK_HZ * 1e3 for k in kms_of}
                 valu = {"wave_insts_per_step": cnt, "lane_ops_per_s": lane_ops / tsum,
                         "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "frac": lane_ops / tsum / VALU_PEAK_LANE_OPS,
                         "per_kernel_frac": {k: 64.0 * cnt[k] / (kms_of[k] * 1e-3) / VALU_PEAK_LANE_OPS for k in kms_of},
-                        # the bound that matters: every vector instruction of the launch issued back to back on its SIMD
-                        "issue_bound_ms": bound_ms,
-                        "frac_of_issue_bound": {k: bound_ms[k] / kms_of[k] for k in kms_of},
-                        "issue_cycles_per_instruction": ISSUE_CYCLES_PER_VALU,
-                        "source": "%s (SQ_INSTS_VALU per launch, same kernel sources) over the live kernel times" % csrc}
+                        # the bound that matters: every vector instruction of the launch issued back to back on its SIMD,
+                        # priced per instruction class; [low, high] for the classes whose members differ in cost
+                        "issue_bound_ms": bound_hi, "issue_bound_ms_low": bound_lo,
+                        "frac_of_issue_bound": {k: bound_hi[k] / kms_of[k] for k in kms_of},
+                        "frac_of_issue_bound_low": {k: bound_lo[k] / kms_of[k] for k in kms_of},
+                        "source": "%s (SQ_INSTS_VALU and instruction-class counters per launch, same kernel sources and flags) "
+                                  "over the live kernel times" % csrc}
             except Exception:
                 valu = None
         out = {

@@ -3,7 +3,7 @@
 cannot share a pass on gfx950; the SQ counters take a third), tagged with the hash of the kernel sources so that
 bench.py quotes it only for the build it was taken from.
 
-  counters.py <fetch_dir> <write_dir> <sq_dir> <out.json> <workload> <mode> A N [note]
+  counters.py <fetch_dir> <write_dir> <sq_dir>[,<sq_dir2>...] <out.json> <workload> <mode> A N [note]
 
 FETCH_SIZE is in KB and, on gfx950, tallies the 128-B requests of wide coalesced reads at 64 B, so the true value
 lies between the reported one and twice it (MI355X_MICROARCH.md, HBM section); both bounds are written
@@ -41,7 +41,12 @@ def means(d):
 def main():
     fetch, n1, _ = means(sys.argv[1])
     write, n2, _ = means(sys.argv[2])
-    sq, n3, names = means(sys.argv[3])
+    sq, n3, names = {}, {}, {}
+    for d in sys.argv[3].split(","):   # several SQ passes (8 counters each): wave / wait counters, instruction classes
+        sq_d, n_d, names_d = means(d)
+        for k, v in sq_d.items():
+            sq.setdefault(k, {}).update(v)
+        n3.update(n_d); names.update(names_d)
     out_path, workload, mode, A, N = sys.argv[4], sys.argv[5], sys.argv[6], int(sys.argv[7]), int(sys.argv[8])
     step_bytes = 60 if mode == "step" else 52
     alg = {"nbr_kernel": 0, "step_kernel": step_bytes * A * N, "obs_kernel": 256 * A * N, "lp3_kernel": 0}

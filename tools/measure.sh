@@ -27,8 +27,9 @@ echo bench done
 rocprofv3 --kernel-trace --stats -d $O/kt --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $O/kt.log 2>&1 || { tail $O/kt.log; exit 1; }
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${T}_kernel_stats_rocprofv3.csv
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU -d $O/sq --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/sq.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SALU -d $O/sq2 --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/sq2.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/write.log 2>&1 || exit 1
-python3 $R/tools/counters.py $O/fetch $O/write $O/sq $O/${T}_counters_C3_step.json C3 step 4096 64 > /dev/null || exit 1
-rm -rf $O/kt $O/sq $O/fetch $O/write
+python3 $R/tools/counters.py $O/fetch $O/write $O/sq,$O/sq2 $O/${T}_counters_C3_step.json C3 step 4096 64 > /dev/null || exit 1
+rm -rf $O/kt $O/sq $O/sq2 $O/fetch $O/write
 ls $O
