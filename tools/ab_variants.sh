@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of library variants on one box: product vs variants/libcaenv_<name>.so, C3 full step (and more with args)
+# A/B of library variants on one box: the product library against variants/libcaenv_<name>.so (built by hand with extra
+# flags), alternating twice.  usage: tools/ab_variants.sh <tag> <name> [<name> ...]   (BENCH_ARGS="--workload C5" to change the workload)
 set -o pipefail
 R=$GRAFT_REPO_ROOT; T=${1:-r03d}; shift; O=$R/gpurun_out/$T
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
