@@ -64,7 +64,7 @@ struct ca_env {
     bool help = false;     // large arenas: helper lanes in the uniform-grid neighbour scan (ca_nbr.h, HELP = 2)
     bool quad = false;     // four lanes per agent (ca_quad.h): small batches / small arenas
     bool quad_roll = false;  // ... for ca_rollout's one-launch-for-T-steps form (pays a little longer than for single steps)
-    int BSq = 64, grid_q = 1;
+    int BSq = 64, grid_q = 1, SQ = 4;   // SQ: obstacle-neighbour capacity of the quad variant (4 or 16)
     size_t lds_q = 0;
     size_t lds = 0;
     uint64_t steps_done = 0;  // env steps executed (agent_steps = steps_done * A * N)
@@ -250,31 +250,28 @@ template <int KMAX, int ST>
 static hipError_t launch_step_k(ca_env* e, const StepArgs& a) {
     return e->fuse_nbr ? launch_step_kf<KMAX, ST, true>(e, a) : launch_step_kf<KMAX, ST, false>(e, a);
 }
-template <int KMAX>
-static hipError_t launch_quad_k(ca_env* e, const StepArgs& a) {
-    const dim3 grid(e->grid_q), block(e->BSq);
-    ProfScope ps(e, KIND_STEP);
-    switch (e->BSq) {  // neighbour search + lines + LP + integration + reward/done, four lanes per agent, a.T steps
-        case 64: hipLaunchKernelGGL((quad_kernel<KMAX, 64>), grid, block, e->lds_q, e->stream, a); break;
-        case 128: hipLaunchKernelGGL((quad_kernel<KMAX, 128>), grid, block, e->lds_q, e->stream, a); break;
-        case 256: hipLaunchKernelGGL((quad_kernel<KMAX, 256>), grid, block, e->lds_q, e->stream, a); break;
-        default: hipLaunchKernelGGL((quad_kernel<KMAX, 512>), grid, block, e->lds_q, e->stream, a); break;
-    }
-    return hipGetLastError();
-}
-template <int KMAX>
-static hipError_t set_quad_lds_attr(int BS, size_t lds) {
-    const void* f;
+template <int KMAX, int SQ>
+static const void* quad_fn_k(int BS) {
     switch (BS) {
-        case 64: f = reinterpret_cast<const void*>(&quad_kernel<KMAX, 64>); break;
-        case 128: f = reinterpret_cast<const void*>(&quad_kernel<KMAX, 128>); break;
-        case 256: f = reinterpret_cast<const void*>(&quad_kernel<KMAX, 256>); break;
-        default: f = reinterpret_cast<const void*>(&quad_kernel<KMAX, 512>); break;
+        case 64: return reinterpret_cast<const void*>(&quad_kernel<KMAX, 64, SQ>);
+        case 128: return reinterpret_cast<const void*>(&quad_kernel<KMAX, 128, SQ>);
+        case 256: return reinterpret_cast<const void*>(&quad_kernel<KMAX, 256, SQ>);
+        default: return reinterpret_cast<const void*>(&quad_kernel<KMAX, 512, SQ>);
     }
-    return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+static const void* quad_fn(const ca_env* e) {
+    if (e->KT == 5) return e->SQ == 4 ? quad_fn_k<5, 4>(e->BSq) : quad_fn_k<5, 16>(e->BSq);
+    return e->SQ == 4 ? quad_fn_k<10, 4>(e->BSq) : quad_fn_k<10, 16>(e->BSq);
+}
+// neighbour search + lines + LP + integration + reward/done, four lanes per agent, a.T steps
+static hipError_t launch_quad(ca_env* e, const StepArgs& a) {
+    ProfScope ps(e, KIND_STEP);
+    StepArgs arg = a;
+    void* params[] = {&arg};
+    return hipLaunchKernel(quad_fn(e), dim3(e->grid_q), dim3(e->BSq), params, e->lds_q, e->stream);
 }
 static hipError_t launch_step(ca_env* e, const StepArgs& a) {
-    if (e->quad || (a.T > 1 && e->quad_roll)) return e->KT == 5 ? launch_quad_k<5>(e, a) : launch_quad_k<10>(e, a);
+    if (e->quad || (a.T > 1 && e->quad_roll)) return launch_quad(e, a);
     if (e->ST > 0) return e->KT == 5 ? launch_step_k<5, 4>(e, a) : launch_step_k<10, 4>(e, a);
     if (e->K <= 5) return launch_step_k<5, 0>(e, a);
     if (e->K <= 10) return launch_step_k<10, 0>(e, a);
@@ -498,14 +495,17 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         // waves.  Measured crossover (profiles/r03_d_lane_vs_quad_by_batch_size.txt): 16-agent arenas -- quad ahead up to
         // 2048 arenas (512 lane-waves), behind from 4096 (1024); 64-agent arenas -- ahead up to 512 arenas, level at 1024.
         const char* v = getenv("CA_QUAD");  // 0 / 1 forces the choice (tests run the parity suite both ways)
-        const bool fits = e->ST > 0 && 4 * P <= 512;  // (a 1024-lane workgroup caps the kernel at 128 VGPRs: it spills)
+        e->SQ = e->S <= 4 ? 4 : 16;
+        // (register budget: a 1024-lane workgroup caps the kernel at 128 VGPRs, a 512-lane one at 256 -- the variant with 16
+        // obstacle neighbours and K = 10 needs all 256 already at 256 lanes)
+        const bool fits = e->K <= 10 && 4 * P <= ((e->SQ == 16 && e->KT == 10) ? 256 : 512);
         const long lane_waves = (long)e->grid * (e->BS / 64);
         e->quad = fits && (v ? v[0] == '1' : lane_waves < 1024);
         e->quad_roll = fits && (v ? v[0] == '1' : lane_waves <= 1024);  // T steps per launch: ahead at 1024 lane-waves too
         e->BSq = 4 * P > 64 ? 4 * P : 64;
         const int apbq = (e->BSq / 4) / P;
         e->grid_q = (cfg->n_arenas + apbq - 1) / apbq;
-        e->lds_q = quad_lds_bytes(e->BSq, e->KT);
+        e->lds_q = quad_lds_bytes(e->BSq, e->KT, e->SQ);
     }
     // + the statically allocated LDS of the fused neighbour search: positions, and for >= 256 lanes the grid tables
     const size_t lds_static = (e->help ? (size_t)e->KT * e->BS * 8 : 0) + (size_t)e->BS * 8 + (e->BS >= 1024 ? (size_t)e->BS * 2 + 16 + 1024 + 1028 : (e->BS >= 256 ? (size_t)e->BS * 2 + 16 + 4096 + 4100 : 0)) + 64;
@@ -555,7 +555,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         else r = set_lds_attr_k<16, 0>(e->BS, e->lds);
     }
     if (r == hipSuccess && e->quad_roll && e->lds_q > 48 * 1024)
-        r = e->KT == 5 ? set_quad_lds_attr<5>(e->BSq, e->lds_q) : set_quad_lds_attr<10>(e->BSq, e->lds_q);
+        r = hipFuncSetAttribute(quad_fn(e), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_q);
     if (r == hipSuccess) {
         const int obs_bs = obs_block_threads(cfg->n_agents);
         const size_t ol = obs_lds_bytes(cfg->n_agents, obs_bs, 16 * (e->K + e->S));

@@ -24,8 +24,9 @@
 // preferred velocity, target and the done flag stay in registers between steps, the arena image in LDS, and the only
 // global traffic inside the loop is the rare event (re-goal, arrival, reset).  Neighbour lists are written by the last
 // step of the launch (every step under CA_F_FREEZE, where an arena's last active step is not known in advance).
-// Supported: N <= 128 agents per arena, K <= 10, at most 4 obstacle neighbours (the shapes of the register-line
-// kernel); ca_env.hip picks it where one lane per agent would leave the chip short of waves (CA_QUAD=0/1 forces it).
+// Supported: N <= 128 agents per arena (64 with K = 10 and more than four obstacle neighbours), K <= 10, up to 16 obstacle
+// neighbours (two instantiations: 4 and 16); ca_env.hip picks it where one lane per agent would leave SIMDs without a
+// wave (CA_QUAD=0/1 forces it).
 #pragma once
 #include "ca_step.h"
 
@@ -155,16 +156,18 @@ __device__ __forceinline__ int lp2_quad(const LdsLines& ls, int n, int q, float 
 
 // LDS of the quad kernel (bytes): line table [waves][2 ML][16] float4 | px py vx vy [BS/4] | per-arena reductions
 // [BS/4][4] int | rewards [BS/4] double
-__host__ __device__ inline size_t quad_lds_bytes(int BS, int KMAX) {
+__host__ __device__ inline size_t quad_lds_bytes(int BS, int KMAX, int SQ) {
     const size_t ns = (size_t)BS / 4;
-    return (size_t)(BS / 64) * (2 * (4 + KMAX)) * POOL_SLOTS * 16 + ns * 16 + ns * 16 + ns * 8;
+    return (size_t)(BS / 64) * (2 * (SQ + KMAX)) * POOL_SLOTS * 16 + ns * 16 + ns * 16 + ns * 8;
 }
 
-template <int KMAX, int BS>
+// SQ: obstacle-neighbour capacity of the variant (S <= SQ): 4 (the synthetic crowds: one boundary polygon) or 16 (the
+// reference's own worlds: doorway, blocks, tube -- env.py:77-123, ALAN:175-457)
+template <int KMAX, int BS, int SQ>
 __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
     static_assert(POOL_SLOTS == 16, "a wave holds 16 quads: one line-table slot each");
+    static_assert(SQ == 4 || SQ == 16, "obstacle lists of 4 or 16");
     constexpr int M = KMAX <= 4 ? 4 : (KMAX <= 8 ? 8 : 16);  // merge width of the agent-neighbour lists
-    constexpr int SQ = 4;                                    // obstacle-neighbour capacity of this variant
     constexpr int ML = SQ + KMAX;
     constexpr int NS = BS / 4;                               // agent slots per workgroup
     constexpr int KQ = (KMAX + 3) / 4;                       // agent-line rounds
@@ -313,47 +316,60 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
 #if !defined(CA_STAMPS) || CA_STAMPS != 3
         CA_STAMP(3);
 #endif
-        // ---- obstacle ORCA lines (App. A.3): lane q builds the line of obstacle neighbour q ----
+        // ---- obstacle ORCA lines (App. A.3): in round r lane q builds the line of obstacle neighbour 4 r + q ----
         int no = 0;
         {
             const float invTO = 1.0f / p.time_horizon_obst;
-            const int e = pick4_index<0>(okey, q);
-            const bool have = active && q < ocnt;
-            float lpx = 0.0f, lpy = 0.0f, ldx = 1.0f, ldy = 0.0f;
-            V2 c1 = mk(0.0f, 0.0f), c2 = mk(0.0f, 0.0f);
-            bool ex = false;
-            if (have) {
-                const ObstDev E = load_obst(tab, e);
-                c1 = invTO * (mk(E.px, E.py) - pos);
-                c2 = invTO * (mk(E.qx, E.qy) - pos);
-                ex = obst_orca_line4(tab, e, pos, vel, R, invTO, [](V2, V2) { return false; }, lpx, lpy, ldx, ldy);
-            }
-            // "already covered" (App. A.3 step 1) against the lines of the lanes before this one, resolved in list order
             const float thr = invTO * R;
-            bool cov0, cov1, cov2;
-            {
-                const V2 pt = mk(quad_bcast<0>(lpx), quad_bcast<0>(lpy)), dr = mk(quad_bcast<0>(ldx), quad_bcast<0>(ldy));
-                cov0 = det(c1 - pt, dr) - thr >= -EPS && det(c2 - pt, dr) - thr >= -EPS;
-            }
-            {
-                const V2 pt = mk(quad_bcast<1>(lpx), quad_bcast<1>(lpy)), dr = mk(quad_bcast<1>(ldx), quad_bcast<1>(ldy));
-                cov1 = det(c1 - pt, dr) - thr >= -EPS && det(c2 - pt, dr) - thr >= -EPS;
-            }
-            {
-                const V2 pt = mk(quad_bcast<2>(lpx), quad_bcast<2>(lpy)), dr = mk(quad_bcast<2>(ldx), quad_bcast<2>(ldy));
-                cov2 = det(c1 - pt, dr) - thr >= -EPS && det(c2 - pt, dr) - thr >= -EPS;
-            }
-            // an edge covered by an existing earlier line yields no line at all (it is skipped before anything else)
-            int exi = (have && ex) ? 1 : 0;   // would produce a line if it is not skipped
-            int alive = have ? 1 : 0;          // not skipped so far
-            // resolve in list order: line J exists iff it was not skipped and produced a line
-            { const int e0 = quad_bcast<0>(exi & alive); if (q > 0 && e0 && cov0) alive = 0; }
-            { const int e1 = quad_bcast<1>(exi & alive); if (q > 1 && e1 && cov1) alive = 0; }
-            { const int e2 = quad_bcast<2>(exi & alive); if (q > 2 && e2 && cov2) alive = 0; }
-            const bool exists = (exi & alive) != 0;
-            const unsigned qm = (unsigned)(__ballot(exists) >> (tid & 60)) & 0xFu;
-            no = __popc(qm);
-            if (exists) ls.put(__popc(qm & ((1u << q) - 1u)), Line{mk(lpx, lpy), mk(ldx, ldy)});
+            static_for<SQ / 4>([&](auto rc) __attribute__((always_inline)) {
+                constexpr int r = decltype(rc)::value;
+                if (__ballot(4 * r < ocnt) != 0ull) {  // some quad of the wave has a neighbour in this round
+                    const int e = pick4_index<4 * r>(okey, q);
+                    const bool have = active && 4 * r + q < ocnt;
+                    float lpx = 0.0f, lpy = 0.0f, ldx = 1.0f, ldy = 0.0f;
+                    V2 c1 = mk(0.0f, 0.0f), c2 = mk(0.0f, 0.0f);
+                    bool ex = false;
+                    if (have) {
+                        const ObstDev E = load_obst(tab, e);
+                        c1 = invTO * (mk(E.px, E.py) - pos);
+                        c2 = invTO * (mk(E.qx, E.qy) - pos);
+                        ex = obst_orca_line4(tab, e, pos, vel, R, invTO, [](V2, V2) { return false; }, lpx, lpy, ldx, ldy);
+                    }
+                    // "already covered" (App. A.3 step 1): an edge covered by an existing earlier line yields no line at
+                    // all.  Earlier lines = those of the rounds before (in the quad's table already) ...
+                    int alive = have ? 1 : 0;  // not skipped so far
+                    if constexpr (r > 0) {
+                        for (int j = 0; j < no; ++j) {
+                            const Line Mj = ls.get(j);
+                            if (det(c1 - Mj.point, Mj.dir) - thr >= -EPS && det(c2 - Mj.point, Mj.dir) - thr >= -EPS) alive = 0;
+                        }
+                    }
+                    // ... and those of the lanes before this one in this round, resolved in list order
+                    bool cov0, cov1, cov2;
+                    {
+                        const V2 pt = mk(quad_bcast<0>(lpx), quad_bcast<0>(lpy)), dr = mk(quad_bcast<0>(ldx), quad_bcast<0>(ldy));
+                        cov0 = det(c1 - pt, dr) - thr >= -EPS && det(c2 - pt, dr) - thr >= -EPS;
+                    }
+                    {
+                        const V2 pt = mk(quad_bcast<1>(lpx), quad_bcast<1>(lpy)), dr = mk(quad_bcast<1>(ldx), quad_bcast<1>(ldy));
+                        cov1 = det(c1 - pt, dr) - thr >= -EPS && det(c2 - pt, dr) - thr >= -EPS;
+                    }
+                    {
+                        const V2 pt = mk(quad_bcast<2>(lpx), quad_bcast<2>(lpy)), dr = mk(quad_bcast<2>(ldx), quad_bcast<2>(ldy));
+                        cov2 = det(c1 - pt, dr) - thr >= -EPS && det(c2 - pt, dr) - thr >= -EPS;
+                    }
+                    const int exi = (have && ex) ? 1 : 0;  // would produce a line if it is not skipped
+                    // line J of the round exists iff it was not skipped and produced a line
+                    { const int e0 = quad_bcast<0>(exi & alive); if (q > 0 && e0 && cov0) alive = 0; }
+                    { const int e1 = quad_bcast<1>(exi & alive); if (q > 1 && e1 && cov1) alive = 0; }
+                    { const int e2 = quad_bcast<2>(exi & alive); if (q > 2 && e2 && cov2) alive = 0; }
+                    const bool exists = (exi & alive) != 0;
+                    const unsigned qm = (unsigned)(__ballot(exists) >> (tid & 60)) & 0xFu;
+                    if (exists) ls.put(no + __popc(qm & ((1u << q) - 1u)), Line{mk(lpx, lpy), mk(ldx, ldy)});
+                    no += __popc(qm);
+                    if constexpr (r + 1 < SQ / 4) wave_lds_sync();  // the next round reads these rows
+                }
+            });
         }
         CA_STAMP(4);
         // ---- agent ORCA lines (App. A.4): lane q builds the lines of neighbours q, q + 4, ... ----

@@ -67,7 +67,8 @@ def parse(asm_path=ASM):
 def by_design(name):
     """The LDS-line-table variant step_kernel<K, BS, 0, *> keeps LP3's projected lines in a private array (ca_lp.h lp3:
     only the few lanes whose LP2 is infeasible touch it); every other hot kernel must run without scratch memory."""
-    return re.match(r"step_kernel<\d+, \d+, 0, (true|false)(, \d+)?>", name) is not None
+    return re.match(r"step_kernel<\d+, \d+, 0, (true|false)(, \d+)?>", name) is not None or \
+        name.startswith("quad_kernel<10, 512, 16>")   # instantiated for the launch switch, never selected (ca_create: 256 lanes at most)
 
 
 def spilling(rows):
