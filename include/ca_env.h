@@ -250,7 +250,8 @@ int ca_profile_read(ca_env* env, int32_t counts[4], float mean_ms[4]);
 int ca_launch_info(ca_env* env, int32_t* block, int32_t* grid, int32_t* lds_bytes, int32_t* obs_grid);
 /* Which solve kernel the handle uses: *lanes_per_agent = 1 (one lane per agent) or 4 (four lanes per agent: chosen
  * at ca_create for batches that would otherwise leave SIMDs without a wave -- fewer than 1024 waves -- when
- * n_agents <= 128, max_neighbors <= 10 and max_obst_neighbors <= 4; results are identical bit for bit).
+ * n_agents <= 128 and max_neighbors <= 10 (n_agents <= 64 when, in addition, max_neighbors > 5 and max_obst_neighbors > 4);
+ * results are identical bit for bit).
  * *rollout_one_launch = 1: ca_rollout(env, T, flags without CA_F_OBS) is ONE kernel launch that keeps every arena in
  * registers / LDS for its T steps (the four-lanes kernel; chosen up to 1024 waves inclusive); 0: it is T launches. */
 int ca_solver_info(ca_env* env, int32_t* lanes_per_agent, int32_t* rollout_one_launch);
