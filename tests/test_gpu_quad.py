@@ -41,6 +41,12 @@ CASES = [  # name, scenario, A, N, overrides, steps
     ("free", "crowd", 5, 20, dict(neighbor_dist=2.0, max_neighbors=5), 200),
     ("k0", "crowd", 6, 12, dict(max_neighbors=0), 100),
     ("k7", "crowd", 6, 40, dict(max_neighbors=7, neighbor_dist=4.0), 150),
+    # the reference's own worlds: more than four obstacle edges in range (the 16-neighbour instantiation, lines in rounds)
+    ("doorway", "doorway", 40, 10, {}, 400),
+    ("deadlock", "deadlock", 6, 30, {}, 500),
+    ("blocks", "blocks", 9, 12, {}, 300),
+    ("congested50", "congested", 3, 50, {}, 200),     # 256-lane workgroups, > 48 KB of LDS
+    ("incoming", "incoming", 4, 17, {}, 200),
 ]
 
 
