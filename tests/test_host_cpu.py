@@ -125,6 +125,6 @@ def test_no_hot_kernel_uses_scratch_memory():
         pytest.skip("no hipcc")
     kr.ensure_asm()
     rows = kr.parse()
-    assert any("step_kernel<10, 64, 4, true" in r["name"] for r in rows) and any("quad_kernel<5, 64>" in r["name"] for r in rows)
+    assert any("step_kernel<10, 64, 4, true" in r["name"] for r in rows) and any("quad_kernel<5, 64, 4>" in r["name"] for r in rows) and any("quad_kernel<10, 256, 16>" in r["name"] for r in rows)
     bad = kr.spilling(rows)
     assert not bad, [(r["name"], r["scratch"], r["vgpr_spill"]) for r in bad]
