@@ -12,8 +12,9 @@ from the operation order of SURVEY Appendix A that the oracle and the kernels fo
 
 The reference delegates this to the absent third-party `rvo2` module, so the oracle cannot be pinned to its outputs
 (parity unpinned for the ORCA arithmetic); this file pins neighbour half-planes (App. A.4) and the
-feasible linear programme (App. A.5 LP1 / LP2) to the paper's geometry on thousands of random configurations.  Obstacle
-half-planes (A.3) and the infeasible case (LP3) stay with the analytic cases of test_oracle_orca.py.
+feasible linear programme (App. A.5 LP1 / LP2) to the paper's geometry on thousands of random configurations, and the main
+branch of the obstacle half-plane (A.3) on random free-standing walls.  The convexity / foreign-leg / already-covered rules
+of A.3 and the infeasible case (LP3) stay with the analytic cases of test_oracle_orca.py.
 """
 import numpy as np
 import pytest
@@ -171,3 +172,136 @@ def test_halfplane_matches_geometry_in_the_three_regimes():
         assert abs(np.dot(got - pt, n)) < 2e-6, (got, pt, n)        # the half-plane is active: the result lies on its line
         assert np.linalg.norm(got - ref) < 5e-6, (got, ref)
     assert kinds == ["arc", "leg", "leg"]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Obstacle half-planes (App. A.3, main branch: a free-standing wall segment with two convex end points, no collision).
+# Definition: VO^tau_{A|O} = { v : exists t in (0, tau] with dist(p_A + t v, O) < r_A } -- for a segment O the cone over the
+# "stadium" (O - p_A) (+) D(0, r) scaled by 1 / tau; the agent takes the whole responsibility, so the half-plane is the
+# tangent to VO at its boundary point closest to the agent's CURRENT velocity.  The boundary point is found numerically
+# (polar search around v with bisection on the membership function), with no reference to the oracle's case analysis.
+# ------------------------------------------------------------------------------------------------------------------
+def _in_vo(X, a, b, r, tau):
+    """X[..., 2] inside VO of the wall [a, b] (relative to the agent): the ray piece {t x : t in (0, tau]} comes within r
+    of the wall, i.e. the segments [0, tau x] and [a, b] are closer than r (vectorised over X)."""
+    X = np.asarray(X, np.float64)
+    Q = tau * X                                               # far end of the ray piece; near end = origin
+    ab = b - a
+
+    def pt_seg(P, s0, s1):                                    # distance of points P[..., 2] from the segment [s0, s1]
+        d = s1 - s0
+        t = np.clip(((P - s0) @ d) / np.dot(d, d), 0.0, 1.0)
+        return np.linalg.norm(P - (s0 + t[..., None] * d), axis=-1)
+
+    def seg_pt(Qe, p):                                        # distance of the point p from the segments [0, Qe[..., 2]]
+        qq = np.maximum(np.sum(Qe * Qe, axis=-1), 1e-300)
+        t = np.clip((Qe @ p) / qq, 0.0, 1.0)
+        return np.linalg.norm(p - t[..., None] * Qe, axis=-1)
+    dist = np.minimum(np.minimum(pt_seg(np.zeros_like(Q), a, b), pt_seg(Q, a, b)), np.minimum(seg_pt(Q, a), seg_pt(Q, b)))
+    # proper crossing of [0, Q] and [a, b]
+    den = Q[..., 0] * ab[1] - Q[..., 1] * ab[0]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s_ = (a[0] * ab[1] - a[1] * ab[0]) / den
+        u_ = (a[0] * Q[..., 1] - a[1] * Q[..., 0]) / den
+    cross = (np.abs(den) > 1e-15) & (s_ >= 0) & (s_ <= 1) & (u_ >= 0) & (u_ <= 1)
+    return cross | (dist < r)
+
+
+def _closest_vo_boundary(v, a, b, r, tau, rmax=2.5):
+    """(closest boundary point of VO to v, outward normal there, v inside?, ambiguity) by a polar search around v:
+    along every direction the first radius at which membership flips (march + bisection, all directions at once)."""
+    inside = bool(_in_vo(v, a, b, r, tau))
+    ths = np.linspace(0, 2 * np.pi, 1440, endpoint=False)
+    D = np.stack([np.cos(ths), np.sin(ths)], 1)
+    radii = np.linspace(0, rmax, 501)[1:]
+    flip = _in_vo(v + radii[None, :, None] * D[:, None, :], a, b, r, tau) != inside        # [angle, radius]
+    has = flip.any(axis=1)
+    first = np.where(has, flip.argmax(axis=1), 0)
+    hi = np.where(has, radii[first], np.inf)
+    lo = np.where(has, radii[first] - rmax / 500, 0.0)
+    for _ in range(30):
+        mid = 0.5 * (lo + hi)
+        f = _in_vo(v + np.where(has, mid, 0.0)[:, None] * D, a, b, r, tau) != inside
+        hi = np.where(has & f, mid, hi); lo = np.where(has & ~f, mid, lo)
+    rs = np.where(has, 0.5 * (lo + hi), np.inf)
+    k = int(np.argmin(rs))
+    if not np.isfinite(rs[k]):
+        return None, None, inside, 0.0
+    # ambiguity: another LOCAL minimum of the radius over the direction (a second boundary piece about as close)
+    fin = np.where(np.isfinite(rs), rs, 1e9)
+    locmin = (fin < np.roll(fin, 1)) & (fin <= np.roll(fin, -1))
+    dth = np.abs(((ths - ths[k]) + np.pi) % (2 * np.pi) - np.pi)
+    others = fin[locmin & (dth > np.radians(3))]
+    gap = (others.min() - rs[k]) if others.size else np.inf
+    # refine the direction by a parabola through the winner and its neighbours
+    km, kp = (k - 1) % len(ths), (k + 1) % len(ths)
+    if np.isfinite(rs[km]) and np.isfinite(rs[kp]):
+        den = rs[km] - 2 * rs[k] + rs[kp]
+        off = 0.5 * (rs[km] - rs[kp]) / den if abs(den) > 1e-15 else 0.0
+        th = ths[k] + np.clip(off, -1, 1) * (ths[1] - ths[0])
+        d = np.array([np.cos(th), np.sin(th)])
+        lo_, hi_ = max(0.0, rs[k] - 0.02), rs[k] + 0.02
+        if bool(_in_vo(v + lo_ * d, a, b, r, tau)) == inside and bool(_in_vo(v + hi_ * d, a, b, r, tau)) != inside:
+            for _ in range(40):
+                mid = 0.5 * (lo_ + hi_)
+                if bool(_in_vo(v + mid * d, a, b, r, tau)) != inside:
+                    hi_ = mid
+                else:
+                    lo_ = mid
+            x = v + 0.5 * (lo_ + hi_) * d
+        else:
+            x = v + rs[k] * D[k]
+    else:
+        x = v + rs[k] * D[k]
+    to_b = (x - v) / np.linalg.norm(x - v)
+    n = to_b if inside else -to_b          # outward normal of VO at x: from inside, towards the boundary; from outside, back
+    return x, n, inside, gap
+
+
+def test_wall_halfplane_is_the_tangent_at_the_closest_boundary_point():
+    rng = np.random.RandomState(7)
+    checked = checked_inside = 0
+    for trial in range(100):
+        # a wall of length 1.5 .. 4 somewhere in front of the agent (agent at the origin), 0.8 .. 1.8 away, not in collision
+        ang = rng.uniform(0, 2 * np.pi)
+        centre = rng.uniform(0.9, 1.8) * np.array([np.cos(ang), np.sin(ang)])
+        tdir = np.array([-np.sin(ang), np.cos(ang)]); tdir = tdir * np.cos(0.5) + np.array([np.cos(ang), np.sin(ang)]) * np.sin(rng.uniform(-0.5, 0.5))
+        tdir /= np.linalg.norm(tdir)
+        half = rng.uniform(0.75, 2.0)
+        a, b = centre - half * tdir, centre + half * tdir
+        ab_ = b - a
+        if np.linalg.norm(a + np.clip(-np.dot(a, ab_) / np.dot(ab_, ab_), 0, 1) * ab_) < R + 0.2:
+            continue                                          # (the agent would touch the wall: the collision branch)
+        sp, va = rng.uniform(0.2, 1.0), rng.uniform(0, 2 * np.pi)
+        if trial % 2:                                         # every other trial: heading for the wall (v inside VO)
+            va = ang + rng.uniform(-0.4, 0.4)
+        v = sp * np.array([np.cos(va), np.sin(va)])
+        xb, n, inside, gap = _closest_vo_boundary(v, a, b, R, TAU)
+        if xb is None or gap < 0.02 or np.linalg.norm(xb) > 0.85 * VMAX:
+            continue                                          # two boundary pieces equally close, or too near the speed disc
+        tang = np.array([n[1], -n[0]])
+        got = []
+        for sgn in (-1.0, 1.0):
+            pref = xb - 0.15 * n + sgn * 0.1 * tang          # inside the forbidden side: the half-plane must be active
+            if np.linalg.norm(pref) >= VMAX:
+                break
+            s = PyRVOSimulator(timeStep=DT, neighborDist=5.0, maxNeighbors=0, timeHorizon=TAU, timeHorizonObst=TAU,
+                               radius=R, maxSpeed=VMAX)
+            s.addAgent((0.0, 0.0))
+            s.addObstacle([tuple(map(float, a)), tuple(map(float, b))]); s.processObstacles()
+            s.setAgentVelocity(0, tuple(map(float, v))); s.setAgentPrefVelocity(0, tuple(map(float, pref)))
+            s.doStep()
+            if s.getAgentNumObstacleNeighbors(0) != 1:
+                break
+            got.append(np.array(s.getAgentVelocity(0), np.float64))
+        if len(got) != 2:
+            continue
+        for g in got:                                         # both results lie on the tangent at the closest boundary point
+            assert abs(np.dot(g - xb, n)) < 5e-4, (trial, a, b, v, xb, n, got)   # observed worst: see DESIGN.md section 2
+        along = got[1] - got[0]
+        assert abs(np.dot(along, n)) < 2e-3 * max(1.0, np.linalg.norm(along)) and np.linalg.norm(along) > 0.15
+        for g in got:                                         # and are safe: outside VO up to the search tolerance
+            assert not bool(_in_vo(g + 2e-3 * n, a, b, R, TAU))
+        checked += 1
+        checked_inside += int(inside)
+    assert checked >= 50 and checked_inside >= 10, (checked, checked_inside)
