@@ -102,6 +102,39 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Wave-wide minimum / maximum / inclusive prefix sum through DPP row shifts and row broadcasts (six VALU
+// instructions each; EVERY lane of the wave must be active: call them outside divergent code and give idle lanes the
+// operation's identity).  The reductions leave their result in lane 63.  (An LDS atomic on ONE address with a value per
+// lane is what these replace: the compiler turns that into a loop over the active lanes, nine instructions per lane.)
+#define CA_ROW_DPP(old, v, ctrl, rows) __builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, rows, 0xF, false)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = min(v, (unsigned)CA_ROW_DPP(~0u, v, 0x111, 0xF));  // row_shr:1
+    v = min(v, (unsigned)CA_ROW_DPP(~0u, v, 0x112, 0xF));  // row_shr:2
+    v = min(v, (unsigned)CA_ROW_DPP(~0u, v, 0x114, 0xF));  // row_shr:4
+    v = min(v, (unsigned)CA_ROW_DPP(~0u, v, 0x118, 0xF));  // row_shr:8: lane 15 of a row holds the row's minimum
+    v = min(v, (unsigned)CA_ROW_DPP(~0u, v, 0x142, 0xA));  // row_bcast:15 into rows 1 and 3
+    v = min(v, (unsigned)CA_ROW_DPP(~0u, v, 0x143, 0xC));  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)CA_ROW_DPP(0u, v, 0x111, 0xF));
+    v = max(v, (unsigned)CA_ROW_DPP(0u, v, 0x112, 0xF));
+    v = max(v, (unsigned)CA_ROW_DPP(0u, v, 0x114, 0xF));
+    v = max(v, (unsigned)CA_ROW_DPP(0u, v, 0x118, 0xF));
+    v = max(v, (unsigned)CA_ROW_DPP(0u, v, 0x142, 0xA));
+    v = max(v, (unsigned)CA_ROW_DPP(0u, v, 0x143, 0xC));
+    return v;
+}
+__device__ __forceinline__ int wave_prefix_sum(int v) {  // inclusive, every lane
+    v += CA_ROW_DPP(0, v, 0x111, 0xF);
+    v += CA_ROW_DPP(0, v, 0x112, 0xF);
+    v += CA_ROW_DPP(0, v, 0x114, 0xF);
+    v += CA_ROW_DPP(0, v, 0x118, 0xF);
+    v += CA_ROW_DPP(0, v, 0x142, 0xA);
+    v += CA_ROW_DPP(0, v, 0x143, 0xC);
+    return v;
+}
+
 // packed list entries: the width of an agent-neighbour id is a compile-time property of the kernel (ids of at most
 // 256 agents fit a byte), obstacle-edge ids are always 16 bits.  (No run-time width test at the loads: a branch per
 // entry keeps the compiler from having a list's loads in flight together -- it cost the observation kernel 11 % --

@@ -148,9 +148,14 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
             for (int cidx = tid0; cidx < GMAX * GMAX; cidx += BS * HELP) s_ccnt[cidx] = 0;
             __syncthreads();
             const bool in_arena = (a < p.a1) && (i < N) && !helper;  // frozen arenas skip the scan but keep the barriers
-            if (in_arena) {
-                atomicMin(&s_box[0], ord(pos.x)); atomicMin(&s_box[1], ord(pos.y));
-                atomicMax(&s_box[2], ord(pos.x)); atomicMax(&s_box[3], ord(pos.y));
+            {  // the arena's bounding box: a reduction per wave, then one atomic per wave and corner
+                const unsigned ox = ord(pos.x), oy = ord(pos.y);
+                const unsigned bx0 = wave_min_u32(in_arena ? ox : 0xFFFFFFFFu), by0 = wave_min_u32(in_arena ? oy : 0xFFFFFFFFu);
+                const unsigned bx1 = wave_max_u32(in_arena ? ox : 0u), by1 = wave_max_u32(in_arena ? oy : 0u);
+                if ((tid0 & 63) == 63) {
+                    atomicMin(&s_box[0], bx0); atomicMin(&s_box[1], by0);
+                    atomicMax(&s_box[2], bx1); atomicMax(&s_box[3], by1);
+                }
             }
             __syncthreads();
             // Cells half a neighbour range wide (the 5 x 5 block around an agent's cell covers its range with 156 / 225 of

@@ -10,11 +10,12 @@ namespace ca {
 //
 // A workgroup (256 lanes) owns 16 agents of ONE arena; 16 lanes per agent.  The arena's
 // positions/velocities are staged in LDS once (the neighbour gathers then never leave the CU).
-// Phase A -- lane per (source, ray) pair: the 16 lanes of an agent walk the pairs (8 octagon chords
-//   per ORCA agent neighbour, one segment per ORCA obstacle neighbour), rotate each segment into
-//   the goal-aligned frame and test it only against the rays that can possibly reach it: the
-//   rays inside the segment's angular span as seen from the origin (a conservative superset, see
-//   ray_span).  The ray/segment test itself is the reference's arithmetic, so culling never
+// Phase A -- lane per (source, ray) pair (8 octagon chords per ORCA agent neighbour, one segment per ORCA
+//   obstacle neighbour): the segment is rotated into the goal-aligned frame and tested only against the
+//   rays that can possibly reach it: the rays inside its angular span as seen from the origin (a
+//   conservative superset, see the pre-pass).  The (neighbour, ray) pairs of the workgroup's 16 agents
+//   form ONE list walked by all its lanes, so a wave takes a second trip only for what does not fit the
+//   whole workgroup.  The ray/segment test itself is the reference's arithmetic, so culling never
 //   changes a result.  A hit is merged into the ray's slot with one LDS ds_min_u64 on the key
 //   (distance bits << 32 | segment index): the minimum distance wins and equal distances resolve
 //   to the first segment, exactly like a serial first-minimum scan.
@@ -54,12 +55,13 @@ struct ObsArgs {
 // The observation workgroup: OBS_BS lanes = OBS_BS/16 agents of ONE arena (template parameter: 256,
 // 512 or 1024 lanes, so that a workgroup can own a whole arena of up to 64 agents and stage it once).
 
-// LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | hit points [16][16] float2 | agent frames [16] float4 | nb idx [16][16] | obstacle idx [16][16]
-//              | ray and octagon tables [64] | pair counts [2][16] | (source, ray) pair lists [16][16 (K + S)] u16
-//              (a list holds the agent-neighbour pairs from its front and the obstacle pairs from its back)
+// LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | agent frames [16] float4 | nb idx [16][16] | obstacle idx [16][16]
+//              | ray and octagon tables [64] | pair counts [2][16] | (source, ray) pairs [16 x 16 (K + S)] u16: the
+//              workgroup's (agent, neighbour, ray) list from the front, every agent's obstacle pairs in a block of its
+//              own from the back
 __host__ __device__ inline size_t obs_lds_bytes(int N, int obs_bs, int paircap) {
     const size_t apb = obs_bs / 16;
-    return (size_t)N * 16 + 2 * apb * 16 * 8 + apb * 16 + apb * 16 * 4 + apb * 16 * 4 + 64 * 4 + 2 * apb * 4 + apb * (size_t)paircap * 2;
+    return (size_t)N * 16 + apb * 16 * 8 + apb * 16 + apb * 16 * 4 + apb * 16 * 4 + 64 * 4 + 2 * apb * 4 + apb * (size_t)paircap * 2;
 }
 #ifndef CA_OBS_BS_MAX
 #define CA_OBS_BS_MAX 256
@@ -121,15 +123,15 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     float* s_vx = s_py + N;
     float* s_vy = s_vx + N;
     unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_vy + N);  // N*16 B: 8-aligned
-    float2* s_hit = reinterpret_cast<float2*>(s_key + OBS_APB * 16);             // hit point of the key's chord
-    float4* s_frame = reinterpret_cast<float4*>(s_hit + OBS_APB * 16);           // (cos, sin, pos x, pos y) per agent
+    float4* s_frame = reinterpret_cast<float4*>(s_key + OBS_APB * 16);           // (cos, sin, pos x, pos y) per agent
     int* s_nb = reinterpret_cast<int*>(s_frame + OBS_APB);
     int* s_ob = s_nb + OBS_APB * 16;
     float* s_rays = reinterpret_cast<float*>(s_ob + OBS_APB * 16);  // [32] rays then [32] octagon
     float* s_oct = s_rays + 32;
-    int* s_cnt = reinterpret_cast<int*>(s_oct + 32);                       // [16] neighbour pairs per agent
+    int* s_cnt = reinterpret_cast<int*>(s_oct + 32);                       // [0]: neighbour pairs of the workgroup
     int* s_cnt2 = s_cnt + OBS_APB;                                         // [16] obstacle pairs per agent
-    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_cnt2 + OBS_APB);  // [16][paircap]
+    unsigned short* s_pair = reinterpret_cast<unsigned short*>(s_cnt2 + OBS_APB);  // [16 * paircap]
+    const int SPAIRS = 16 * S;  // an agent's block of obstacle pairs
     CA_OSTAMP(0);
     if (tid < 32) { s_rays[tid] = p.rays[tid]; s_oct[tid] = p.oct[tid]; }
 
@@ -155,34 +157,42 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     const int M = 8 * nn + ns;
     float mx = 0.0f, my = 0.0f;
     if (M > 0) { mx = s_px[i]; my = s_py[i]; }
-    if (r == 0) s_frame[g] = make_float4(c, s, mx, my);  // phase A lanes also work for the wave's other agents
+    if (r == 0) s_frame[g] = make_float4(c, s, mx, my);  // phase A lanes also work for the workgroup's other agents
     // ---- pre-pass: which (source, ray) pairs are worth the exact test?  Supersets only; never results. ----
     // (1) lane per agent NEIGHBOUR: all 8 octagon vertices lie on the circle of radius R around it, so the
     // rays within asin(R/d) of its direction are a superset for each of its 8 chords.  asin(t) <= t + (pi/2 - 1) t^3
     // on [0, 1] ((asin t - t) / t^3 grows from 1/6 to pi/2 - 1); margin 0.02 dial units = 7.8e-3 rad covers the
     // dial's 1e-4 and the approximate reciprocal square root.
-    for (int k = r; k < nn; k += 16) {
-        const int nb = s_nb[g * 16 + k];
-        const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
-        const float d2 = rx * rx + ry * ry, R = p.radius;
-        const float ax = c * rx - s * ry, ay = s * rx + c * ry;
-        const bool all = !(d2 > 1.0404f * R * R);  // the agent is inside (or within 2 % of) that circle
-        const float ua = ray_dial(ax, ay);
-        const float t = R * __builtin_amdgcn_rsqf(d2);
-        const float hw = t * (1.0f + 0.5708f * (t * t)) * 2.54647908947f + 0.02f;
-        int i0 = (int)ceilf(ua - hw), i1 = (int)floorf(ua + hw);
-        if (all || i1 - i0 >= 15) { i0 = 0; i1 = 15; }
-        const int w = i1 - i0 + 1;
-        if (w > 0) {  // neighbour pairs fill the list from the front (list order is irrelevant: commutative minimum)
-            const int base = atomicAdd(&s_cnt[g], w);
-            for (int t2 = 0; t2 < w; ++t2)
-                s_pair[g * PAIRCAP + base + t2] = (unsigned short)((k << 4) | ((i0 + t2) & 15));
+    // The pairs go to the workgroup's list at a position from the wave's prefix sum of the window widths and ONE atomic
+    // per wave (at most 16 neighbours, CA_MAX_NEIGHBORS, so lane r < nn of an agent owns neighbour slot r).
+    {
+        const int k = r;
+        int i0 = 0, w = 0;
+        if (k < nn) {
+            const int nb = s_nb[g * 16 + k];
+            const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
+            const float d2 = rx * rx + ry * ry, R = p.radius;
+            const float ax = c * rx - s * ry, ay = s * rx + c * ry;
+            const bool all = !(d2 > 1.0404f * R * R);  // the agent is inside (or within 2 % of) that circle
+            const float ua = ray_dial(ax, ay);
+            const float t = R * __builtin_amdgcn_rsqf(d2);
+            const float hw = t * (1.0f + 0.5708f * (t * t)) * 2.54647908947f + 0.02f;
+            int i1 = (int)floorf(ua + hw);
+            i0 = (int)ceilf(ua - hw);
+            if (all || i1 - i0 >= 15) { i0 = 0; i1 = 15; }
+            w = max(i1 - i0 + 1, 0);
         }
+        const int incl = wave_prefix_sum(w);
+        int base = 0;
+        if ((tid & 63) == 63) base = atomicAdd(&s_cnt[0], incl);
+        base = __builtin_amdgcn_readlane(base, 63) + (incl - w);
+        for (int t2 = 0; t2 < w; ++t2)  // (list order is irrelevant: the merge is a commutative minimum)
+            s_pair[base + t2] = (unsigned short)((g << 8) | (k << 4) | ((i0 + t2) & 15));
     }
     // (2) lane per RAY, one obstacle edge at a time: the exact test can accept a ray only if the ray's line
     // separates the edge's end points and the crossing is not behind the origin, i.e. (up to rounding, covered
     // by tolE = 50x the error of these products) the two end points are not on the same side of the line and
-    // not both behind.  Obstacle pairs fill the agent's list from the back.
+    // not both behind.  Obstacle pairs fill the agent's block at the back of the list.
     {
         const float dx = s_rays[2 * r], dy = s_rays[2 * r + 1];
         int cnt2 = 0;
@@ -197,14 +207,14 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             const bool keep = !(c2 > tolE && c3 > tolE) && !(c2 < -tolE && c3 < -tolE) && (fmaxf(f2, f3) >= -tolE);
             const unsigned grp = (unsigned)(__ballot(keep) >> (threadIdx.x & 48)) & 0xFFFFu;  // my agent's 16 lanes
             if (keep)
-                s_pair[g * PAIRCAP + PAIRCAP - 1 - (cnt2 + __popc(grp & ((1u << r) - 1u)))] =
+                s_pair[OBS_APB * PAIRCAP - 1 - (g * SPAIRS + cnt2 + __popc(grp & ((1u << r) - 1u)))] =
                     (unsigned short)(((nn + sidx) << 4) | r);
             cnt2 += __popc(grp);
         }
         if (r == 0) s_cnt2[g] = cnt2;
     }
     CA_OSTAMP(3);
-    wave_lds_sync();  // the 16 lanes of an agent are in one wave: no workgroup barrier needed
+    __syncthreads();
     CA_OSTAMP(4);
     // segment m of this agent in the rotated frame (env.py:283-294, 305-315; utils.py:55-62)
     auto build = [&](int m, SegGeom& sg, float& velx, float& vely, bool want_vel) {
@@ -262,17 +272,18 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         return true;
     };
 
-    // the same test and distance without early exits (the division of a rejected chord is computed and dropped)
-    auto hit_nb = [&](const SegGeom& sg, float s10x, float s10y, float& d, float& hx, float& hy) -> bool {
-        const float denom = s10x * sg.s32y - sg.s32x * s10y;          // utils.py:14
+    // the same accept test without early exits, and the distance of an accepted crossing (utils.py:34-38)
+    auto accept_nb = [&](const SegGeom& sg, float s10x, float s10y, float& denom) -> bool {
+        denom = s10x * sg.s32y - sg.s32x * s10y;                      // utils.py:14
         const float s_numer = s10x * sg.s02y - s10y * sg.s02x;        // utils.py:21
         const bool dpos = denom > 0.0f;
-        const bool ok = (denom != 0.0f) && ((s_numer < 0.0f) != dpos) && ((sg.t_numer < 0.0f) != dpos) &&
-                        ((s_numer > denom) != dpos) && ((sg.t_numer > denom) != dpos);  // utils.py:15-31
-        const float t = sg.t_numer / denom;                            // utils.py:34
-        hx = 0.0f + t * s10x; hy = 0.0f + t * s10y;                    // utils.py:36-37
-        d = sqrtf(hx * hx + hy * hy);                                  // utils.py:38
-        return ok;
+        return (denom != 0.0f) && ((s_numer < 0.0f) != dpos) && ((sg.t_numer < 0.0f) != dpos) &&
+               ((s_numer > denom) != dpos) && ((sg.t_numer > denom) != dpos);  // utils.py:15-31
+    };
+    auto hit_dist = [&](float t_numer, float denom, float s10x, float s10y) -> float {
+        const float t = t_numer / denom;                               // utils.py:34
+        const float hx = 0.0f + t * s10x, hy = 0.0f + t * s10y;        // utils.py:36-37
+        return sqrtf(hx * hx + hy * hy);                               // utils.py:38
     };
 
     // ---- phase A: lane per (source, ray) pair ----
@@ -281,33 +292,23 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     // per pair and every chord is accept-tested against the pair's single ray.  Only accepted chords
     // (about two per pair) are re-derived through build()/hit() for the exact hit distance.
     const float tol = 2e-5f * p.rays[0] * (p.rays[0] + 2.0f * p.radius + 1.0f);  // rays[0] = neighbor_dist (env.py:321-332)
-    // The lane whose key is the ray's minimum after this trip's atomics leaves its hit point next to the key
-    // (the LDS executes one wave's instructions in order, so the re-read sees every lane's atomic of the trip;
-    // a later, smaller key overwrites both).  Phase B then needs no second division / square root.
-    auto merge = [&](int ga, int ray, float best, int best_m, float bhx, float bhy) {
-        if (best_m >= 0) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)best_m;
-            atomicMin(&s_key[ga * 16 + ray], key);
-            if (s_key[ga * 16 + ray] == key) s_hit[ga * 16 + ray] = make_float2(bhx, bhy);
-        }
+    auto merge = [&](int ga, int ray, float best, int best_m) {
+        if (best_m >= 0)
+            atomicMin(&s_key[ga * 16 + ray], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)best_m);
     };
     // (neighbour, ray) pairs and (obstacle edge, ray) pairs in loops of their own: a wave that mixes the two
-    // kinds in one pass pays for both code paths.  The neighbour pairs of the wave's FOUR agents form one
-    // work list shared by its 64 lanes (an agent has 13 pairs on average but often a few more than 16, which
-    // would cost its 16 lanes -- and with them the wave -- a second trip).
-    const int g0 = g & ~3;
-    const int n0 = s_cnt[g0], n1 = s_cnt[g0 + 1], n2 = s_cnt[g0 + 2], n3 = s_cnt[g0 + 3];
-    const int ntot = n0 + n1 + n2 + n3;
-    for (int pi = tid & 63; pi < ntot; pi += 64) {
-        int ga = g0, li = pi;
-        { const bool b = li >= n0; ga = b ? g0 + 1 : ga; li = b ? li - n0 : li;
-          const bool b1 = b && li >= n1; ga = b1 ? g0 + 2 : ga; li = b1 ? li - n1 : li;
-          const bool b2 = b1 && li >= n2; ga = b2 ? g0 + 3 : ga; li = b2 ? li - n2 : li; }
+    // kinds in one pass pays for both code paths.  The neighbour pairs of the workgroup's 16 agents form one
+    // work list shared by all its lanes: an agent has 16 pairs on average in a settled crowd (C3), so a list
+    // per agent would send its 16 lanes on a second trip half of the time and a list per wave (tried: 43 % of
+    // the waves took a second, nearly empty trip) still wastes a third of the issue slots of this loop; with one
+    // list only the first wave ever takes a second trip, for the few pairs beyond the workgroup's lane count.
+    const int ntot = s_cnt[0];
+    for (int pi = tid; pi < ntot; pi += OBS_BS) {
+        const int pr = s_pair[pi];
+        const int ga = pr >> 8, k = (pr >> 4) & 15, ray = pr & 15;
         const float4 fr = s_frame[ga];
-        const int pr = s_pair[ga * PAIRCAP + li];
-        const int k = pr >> 4, ray = pr & 15;
         const float s10x = s_rays[2 * ray] - 0.0f, s10y = s_rays[2 * ray + 1] - 0.0f;
-        float best = __int_as_float(0x7f800000), bhx = 0.0f, bhy = 0.0f;
+        float best = __int_as_float(0x7f800000);
         int best_m = -1;
         const int nb = s_nb[ga * 16 + k];
         const float rx = s_px[nb] - fr.z, ry = s_py[nb] - fr.w;
@@ -319,14 +320,13 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         // ray_w x (oct_e + rel) with ray_w the ray turned back by the agent's frame -- no vertex is rotated here.
         // `tol` is 100x the rounding error of either form.  The survivors -- the entry and the exit chord, a
         // third one when the line grazes a vertex -- go through the reference's arithmetic below.
+        // Vertex e of the octagon is R (cos e pi/4, -sin e pi/4) (env.py:335-350) and vertex e + 4 its mirror image,
+        // so the eight cross products are four, each added to and subtracted from the ray x centre term.
         const float wx = fr.x * s10x + fr.y * s10y, wy = fr.x * s10y - fr.y * s10x;
         const float wb = wx * ry - wy * rx;
-        float cr[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
-            cr[e] = (wx * oc.y - wy * oc.x) + wb;
-        }
+        const float R = p.radius, Rh = 0.70710678f * R;
+        const float c0 = R * wy, c2 = R * wx, c1 = Rh * (wx + wy), c3 = Rh * (wy - wx);
+        const float cr[8] = {wb - c0, wb - c1, wb - c2, wb + c3, wb + c0, wb + c1, wb + c2, wb - c3};
         unsigned acc = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -335,8 +335,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             acc |= same_side ? 0u : (1u << e);
         }
         // ascending chord index, strict '<': the first minimum wins.  Two surviving chords (entry and exit)
-        // are evaluated side by side in straight-line code, so that the two instruction streams can share
-        // packed fp32 instructions; the arithmetic of each is the reference's (utils.py:14-38).
+        // are taken together in straight-line code; the arithmetic of each is the reference's (utils.py:14-38).
         while (acc) {
             const int e1 = __ffs(acc) - 1;
             acc &= acc - 1;
@@ -346,26 +345,44 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             SegGeom g1, g2;
             build_nb(ga, fr, k, e1, g1);
             build_nb(ga, fr, k, e2, g2);
-            float d1, d2, h1x, h1y, h2x, h2y;
-            const bool ok1 = hit_nb(g1, s10x, s10y, d1, h1x, h1y), ok2 = hit_nb(g2, s10x, s10y, d2, h2x, h2y) && two;
-            if (ok1 && d1 < best) { best = d1; best_m = 8 * k + e1; bhx = h1x; bhy = h1y; }
-            if (ok2 && d2 < best) { best = d2; best_m = 8 * k + e2; bhx = h2x; bhy = h2y; }
+            float dn1, dn2;
+            const bool ok1 = accept_nb(g1, s10x, s10y, dn1), ok2 = accept_nb(g2, s10x, s10y, dn2) && two;
+            // Both accepted (the ray enters through one chord and leaves through the other): the distance is monotone
+            // in t = t_numer / denom, so when the two quotients differ by more than 1e-5 relative -- 30x what the
+            // division, the products and the square root of utils.py:34-38 can round away -- the nearer chord is
+            // known from a cross-multiplication and only ITS distance is computed.  Anything closer than that (the
+            // ray through a shared vertex), or a crossing at the origin, takes both through the reference's
+            // arithmetic and compares the rounded distances as the reference does.
+            const float lhs = fabsf(g1.t_numer) * fabsf(dn2), rhs = fabsf(g2.t_numer) * fabsf(dn1);  // t1 < t2  <=>  lhs < rhs
+            const bool first = ok1 && (!ok2 || lhs < rhs);
+            const float tnw = first ? g1.t_numer : g2.t_numer, dnw = first ? dn1 : dn2;
+            const int ew = first ? e1 : e2;
+            const bool sure = fminf(lhs, rhs) < 0.99999f * fmaxf(lhs, rhs) && fmaxf(lhs, rhs) > 1e-30f &&
+                              fabsf(tnw) > 1e-12f * fabsf(dnw);
+            if (ok1 && ok2 && !sure) {
+                const float d1 = hit_dist(g1.t_numer, dn1, s10x, s10y), d2 = hit_dist(g2.t_numer, dn2, s10x, s10y);
+                if (d1 < best) { best = d1; best_m = 8 * k + e1; }
+                if (d2 < best) { best = d2; best_m = 8 * k + e2; }
+            } else {
+                const float dw = hit_dist(tnw, dnw, s10x, s10y);
+                if ((ok1 || ok2) && dw < best) { best = dw; best_m = 8 * k + ew; }
+            }
         }
-        merge(ga, ray, best, best_m, bhx, bhy);
+        merge(ga, ray, best, best_m);
     }
     const int no = s_cnt2[g];
     for (int pi = r; pi < no; pi += 16) {
-        const int pr = s_pair[g * PAIRCAP + PAIRCAP - 1 - pi];
+        const int pr = s_pair[OBS_APB * PAIRCAP - 1 - (g * SPAIRS + pi)];
         const int k = pr >> 4, ray = pr & 15;
         const float s10x = s_rays[2 * ray] - 0.0f, s10y = s_rays[2 * ray + 1] - 0.0f;
         SegGeom sg;
         float dum0, dum1, d, hx, hy;
         const int m = 8 * nn + (k - nn);
         build(m, sg, dum0, dum1, false);
-        if (hit(sg, s10x, s10y, d, hx, hy)) merge(g, ray, d, m, hx, hy);
+        if (hit(sg, s10x, s10y, d, hx, hy)) merge(g, ray, d, m);
     }
     CA_OSTAMP(5);
-    wave_lds_sync();
+    __syncthreads();  // a ray's key takes hits from every wave of the workgroup
     CA_OSTAMP(6);
     if (!active) return;
     // ---- phase B: lane per ray ----
@@ -375,8 +392,9 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         SegGeom sg;
         float wx, wy;
         build((int)(unsigned)key, sg, wx, wy, true);
-        const float2 h = s_hit[g * 16 + r];
-        bx = h.x; by = h.y;
+        const float s10x = s_rays[2 * r] - 0.0f, s10y = s_rays[2 * r + 1] - 0.0f;
+        const float t = sg.t_numer / (s10x * sg.s32y - sg.s32x * s10y);  // utils.py:14,34: the accepted hit again
+        bx = 0.0f + t * s10x; by = 0.0f + t * s10y;                      // utils.py:36-37
         if (!(bx == 0.0f && by == 0.0f)) { vx = wx; vy = wy; }  // utils.py:103
     }
     CA_OSTAMP(7);
