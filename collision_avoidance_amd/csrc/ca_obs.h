@@ -160,9 +160,10 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     if (r == 0) s_frame[g] = make_float4(c, s, mx, my);  // phase A lanes also work for the workgroup's other agents
     // ---- pre-pass: which (source, ray) pairs are worth the exact test?  Supersets only; never results. ----
     // (1) lane per agent NEIGHBOUR: all 8 octagon vertices lie on the circle of radius R around it, so the
-    // rays within asin(R/d) of its direction are a superset for each of its 8 chords.  asin(t) <= t + (pi/2 - 1) t^3
-    // on [0, 1] ((asin t - t) / t^3 grows from 1/6 to pi/2 - 1); margin 0.02 dial units = 7.8e-3 rad covers the
-    // dial's 1e-4 and the approximate reciprocal square root.
+    // rays within asin(R/d) of its direction are a superset for each of its 8 chords.  asin(t) <= t + t^3 / 6 +
+    // 3 t^5 / 40 + c t^7 on [0, 1] with c = pi/2 - 1 - 1/6 - 3/40 (the series has positive coefficients and its tail
+    // sums to c at t = 1): within 2e-3 rad of asin for t <= 1/2, i.e. for neighbours that do not overlap the agent.
+    // The margin of 0.002 dial units = 7.8e-4 rad covers the dial's 1e-4 and the approximate reciprocal square root.
     // The pairs go to the workgroup's list at a position from the wave's prefix sum of the window widths and ONE atomic
     // per wave (at most 16 neighbours, CA_MAX_NEIGHBORS, so lane r < nn of an agent owns neighbour slot r).
     {
@@ -176,7 +177,8 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             const bool all = !(d2 > 1.0404f * R * R);  // the agent is inside (or within 2 % of) that circle
             const float ua = ray_dial(ax, ay);
             const float t = R * __builtin_amdgcn_rsqf(d2);
-            const float hw = t * (1.0f + 0.5708f * (t * t)) * 2.54647908947f + 0.02f;
+            const float t2 = t * t;
+            const float hw = t * (1.0f + t2 * (0.16666667f + t2 * (0.075f + t2 * 0.32914f))) * 2.54647908947f + 0.002f;
             int i1 = (int)floorf(ua + hw);
             i0 = (int)ceilf(ua - hw);
             if (all || i1 - i0 >= 15) { i0 = 0; i1 = 15; }
