@@ -508,7 +508,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->lds_q = quad_lds_bytes(e->BSq, e->KT, e->SQ);
     }
     // + the statically allocated LDS of the fused neighbour search: positions, and for >= 256 lanes the grid tables
-    const size_t lds_static = (e->help ? (size_t)e->KT * e->BS * 8 : 0) + (size_t)e->BS * 8 + (e->BS >= 1024 ? (size_t)e->BS * 2 + 16 + 1024 + 1028 : (e->BS >= 256 ? (size_t)e->BS * 2 + 16 + 4096 + 4100 : 0)) + 64;
+    const size_t lds_static = (e->help ? (size_t)e->KT * e->BS * 8 : 0) + (size_t)e->BS * 8 + (e->BS >= 1024 ? (size_t)e->BS * 2 + 16 + 1024 + 1028 : (e->BS >= 256 ? (size_t)e->BS * 2 + (size_t)e->BS * 8 + 16 + 4096 + 4100 : 0)) + 64;
     if (e->lds + lds_static > 160 * 1024) {
         fail(nullptr, CA_ERANGE, "ca_create: the solve kernel would need %zu B of LDS (> 160 KiB) for n_agents=%d, "
              "max_neighbors=%d, max_obst_neighbors=%d: arenas above 256 agents need max_neighbors <= 10 and "

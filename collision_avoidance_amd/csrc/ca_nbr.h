@@ -189,24 +189,55 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
                 if (tid0 == 63) s_cstart[GMAX * GMAX] = incl;
             }
             __syncthreads();
-            if (in_arena) s_sorted[s_cstart[cy * Gx + cx] + rank] = (unsigned short)i;
+            // (up to 512 lanes the positions are sorted along with the indices: a candidate then is one LDS address, known
+            // an iteration ahead, instead of an index and a dependent gather; the 1024-lane shape has no LDS for that)
+            constexpr bool SXY = BS <= 512;
+            __shared__ float2 s_sxy[SXY ? BS : 1];
+            if (in_arena) {
+                const int dst = s_cstart[cy * Gx + cx] + rank;
+                s_sorted[dst] = (unsigned short)i;
+                if constexpr (SXY) s_sxy[dst] = make_float2(pos.x, pos.y);
+            }
             __syncthreads();
             const float rangeSq0 = sqr(p.neighbor_dist);
             float rangeK = rangeSq0;  // distance of the current K-th entry once the list is full
-            for (int ry = -RC; ry <= RC; ++ry) {
+            auto row_range = [&](int ry, int& lo, int& hi) {
                 const int row = cy + ry;
-                int lo = 0, hi = 0;
+                lo = 0; hi = 0;
                 if (active && row >= 0 && row < Gy) {
                     lo = s_cstart[row * Gx + max(cx - RC, 0)];
                     hi = s_cstart[row * Gx + min(cx + RC, Gx - 1) + 1];
                 }
-                for (int t = lo + (helper ? 1 : 0); t < hi; t += HELP) {
-                    const int j = s_sorted[t];
-                    const float dsq = absSq(pos - mk(s_px[j], s_py[j]));
-                    if (j != i && dsq < rangeSq0 && dsq <= rangeK) {
-                        sorted_insert<KMAX>(nkey, make_key(dsq, j));
-                        if (ncnt < K) ++ncnt;
-                        if (ncnt == K) rangeK = key_dist(nkey[KMAX - 1]);
+            };
+            auto visit = [&](int j, const V2& o) {
+                const float dsq = absSq(pos - o);
+                if (j != i && dsq < rangeSq0 && dsq <= rangeK) {
+                    sorted_insert<KMAX>(nkey, make_key(dsq, j));
+                    if (ncnt < K) ++ncnt;
+                    if (ncnt == K) rangeK = key_dist(nkey[KMAX - 1]);
+                }
+            };
+            int lo_n, hi_n;
+            row_range(-RC, lo_n, hi_n);
+            for (int ry = -RC; ry <= RC; ++ry) {
+                const int lo = lo_n, hi = hi_n;
+                if (ry < RC) row_range(ry + 1, lo_n, hi_n);  // the next row's bounds are in flight during this row
+                int t = lo + (helper ? 1 : 0);
+                if constexpr (SXY) {
+                    int jn = 0;
+                    float2 on = make_float2(0.0f, 0.0f);
+                    if (t < hi) { jn = s_sorted[t]; on = s_sxy[t]; }
+                    while (t < hi) {
+                        const int j = jn;
+                        const V2 o = mk(on.x, on.y);
+                        t += HELP;
+                        if (t < hi) { jn = s_sorted[t]; on = s_sxy[t]; }  // the next candidate is in flight during this one
+                        visit(j, o);
+                    }
+                } else {
+                    for (; t < hi; t += HELP) {
+                        const int j = s_sorted[t];
+                        visit(j, mk(s_px[j], s_py[j]));
                     }
                 }
             }

@@ -31,5 +31,7 @@ rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F3
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/write.log 2>&1 || exit 1
 python3 $R/tools/counters.py $O/fetch $O/write $O/sq,$O/sq2 $O/${T}_counters_C3_step.json C3 step 4096 64 > /dev/null || exit 1
+# the headline line again, now that its counter summary exists (bench.py quotes profiles/*_counters_*.json of the same sources)
+cp $O/${T}_counters_C3_step.json $R/profiles/ && timeout -k 10 300 python3 $R/bench.py > $O/${T}_bench_C3_step.json 2>>$O/bench.err || exit 1
 rm -rf $O/kt $O/sq $O/sq2 $O/fetch $O/write
 ls $O

@@ -12,6 +12,9 @@ run() {  # workload mode A N
   rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py $args > $O/write.log 2>&1 || return 1
   python3 $R/tools/counters.py $O/fetch $O/write $O/sq,$O/sq2 $O/${T}_counters_${wl}_${mode}.json $wl $mode $A $N > /dev/null || return 1
   rm -rf $O/sq $O/sq2 $O/fetch $O/write
+  # the bench line of this workload again, with its counter summary in place (bench.py reads profiles/)
+  local out=$O/${T}_bench_${wl}$([ $mode = orca ] && echo _orca).json
+  cp $O/${T}_counters_${wl}_${mode}.json $R/profiles/ && timeout -k 10 300 python3 $R/bench.py --workload $wl --mode $mode > $out 2>>$O/bench.err || return 1
   echo "$wl $mode done"
 }
 run C2 step 1024 16 && run C5 step 256 512 && run C3 orca 4096 64 && run C2 orca 1024 16
