@@ -55,13 +55,13 @@ struct ObsArgs {
 // The observation workgroup: OBS_BS lanes = OBS_BS/16 agents of ONE arena (template parameter: 256,
 // 512 or 1024 lanes, so that a workgroup can own a whole arena of up to 64 agents and stage it once).
 
-// LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | agent frames [16] float4 | nb idx [16][16] | obstacle idx [16][16]
+// LDS (bytes): arena px,py,vx,vy [N] | keys [16][16] u64 | neighbour positions relative to the agent [16][16] float2 | agent frames [16] float4 | nb idx [16][16] | obstacle idx [16][16]
 //              | ray and octagon tables [64] | pair counts [2][16] | (source, ray) pairs [16 x 16 (K + S)] u16: the
 //              workgroup's (agent, neighbour, ray) list from the front, every agent's obstacle pairs in a block of its
 //              own from the back
 __host__ __device__ inline size_t obs_lds_bytes(int N, int obs_bs, int paircap) {
     const size_t apb = obs_bs / 16;
-    return (size_t)N * 16 + apb * 16 * 8 + apb * 16 + apb * 16 * 4 + apb * 16 * 4 + 64 * 4 + 2 * apb * 4 + apb * (size_t)paircap * 2;
+    return (size_t)N * 16 + 2 * apb * 16 * 8 + apb * 16 + apb * 16 * 4 + apb * 16 * 4 + 64 * 4 + 2 * apb * 4 + apb * (size_t)paircap * 2;
 }
 #ifndef CA_OBS_BS_MAX
 #define CA_OBS_BS_MAX 256
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     float* s_vx = s_py + N;
     float* s_vy = s_vx + N;
     unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_vy + N);  // N*16 B: 8-aligned
-    float4* s_frame = reinterpret_cast<float4*>(s_key + OBS_APB * 16);           // (cos, sin, pos x, pos y) per agent
+    float2* s_rel = reinterpret_cast<float2*>(s_key + OBS_APB * 16);             // neighbour slot k of agent g: p_nb - p_g
+    float4* s_frame = reinterpret_cast<float4*>(s_rel + OBS_APB * 16);           // (cos, sin, pos x, pos y) per agent
     int* s_nb = reinterpret_cast<int*>(s_frame + OBS_APB);
     int* s_ob = s_nb + OBS_APB * 16;
     float* s_rays = reinterpret_cast<float*>(s_ob + OBS_APB * 16);  // [32] rays then [32] octagon
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         if (k < nn) {
             const int nb = s_nb[g * 16 + k];
             const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
+            s_rel[g * 16 + k] = make_float2(rx, ry);  // (env.py:288-289) for the pair trips and the winners
             const float d2 = rx * rx + ry * ry, R = p.radius;
             const float ax = c * rx - s * ry, ay = s * rx + c * ry;
             const bool all = !(d2 > 1.0404f * R * R);  // the agent is inside (or within 2 % of) that circle
@@ -223,12 +225,12 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         float x1, y1, x2, y2, vx = 0.0f, vy = 0.0f;
         if (m < 8 * nn) {
             const int k = m >> 3, e = m & 7;
-            const int nb = s_nb[g * 16 + k];
-            const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
+            const float2 rel = s_rel[g * 16 + k];
+            const float rx = rel.x, ry = rel.y;
             const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
             x1 = oc.x + rx; y1 = oc.y + ry;
             x2 = oc.z + rx; y2 = oc.w + ry;
-            if (want_vel) { vx = s_vx[nb]; vy = s_vy[nb]; }  // env.py:252
+            if (want_vel) { const int nb = s_nb[g * 16 + k]; vx = s_vx[nb]; vy = s_vy[nb]; }  // env.py:252
         } else {
             const ObstDev o1 = load_obst(tab, s_ob[g * 16 + (m - 8 * nn)]);
             x1 = o1.px - mx; y1 = o1.py - my;
@@ -245,10 +247,8 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             velx = rvx - sg.r1x; vely = rvy - sg.r1y;                      // utils.py:62
         }
     };
-    // chord e of neighbour slot k of agent ga (one of this wave's four), in ga's frame fr = (cos, sin, x, y)
-    auto build_nb = [&](int ga, const float4& fr, int k, int e, SegGeom& sg) {
-        const int nb = s_nb[ga * 16 + k];
-        const float rx = s_px[nb] - fr.z, ry = s_py[nb] - fr.w;
+    // chord e of a neighbour at (rx, ry) from its agent, in the agent's frame fr = (cos, sin)
+    auto build_nb = [&](const float2& fr, float rx, float ry, int e, SegGeom& sg) {
         const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
         const float x1 = oc.x + rx, y1 = oc.y + ry, x2 = oc.z + rx, y2 = oc.w + ry;
         sg.r1x = fr.x * x1 - fr.y * y1; sg.r1y = fr.y * x1 + fr.x * y1;  // utils.py:59
@@ -308,12 +308,12 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     for (int pi = tid; pi < ntot; pi += OBS_BS) {
         const int pr = s_pair[pi];
         const int ga = pr >> 8, k = (pr >> 4) & 15, ray = pr & 15;
-        const float4 fr = s_frame[ga];
+        const float2 fr = *reinterpret_cast<const float2*>(&s_frame[ga]);
+        const float2 rel = s_rel[pr >> 4];  // = [ga][k]
         const float s10x = s_rays[2 * ray] - 0.0f, s10y = s_rays[2 * ray + 1] - 0.0f;
         float best = __int_as_float(0x7f800000);
         int best_m = -1;
-        const int nb = s_nb[ga * 16 + k];
-        const float rx = s_px[nb] - fr.z, ry = s_py[nb] - fr.w;
+        const float rx = rel.x, ry = rel.y;
         // Which chords can the exact test accept?  It needs the crossing parameter along the chord,
         // s_numer / denom (utils.py:21-31), inside [0, 1], i.e. the ray's LINE must separate the chord's end
         // points: with cr[e] = ray x vertex e (= -s_numer of chord e), a chord whose two end points lie on the
@@ -345,8 +345,8 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             const int e2 = two ? __ffs(acc) - 1 : e1;
             acc &= acc - 1;  // (0 & anything stays 0)
             SegGeom g1, g2;
-            build_nb(ga, fr, k, e1, g1);
-            build_nb(ga, fr, k, e2, g2);
+            build_nb(fr, rx, ry, e1, g1);
+            build_nb(fr, rx, ry, e2, g2);
             float dn1, dn2;
             const bool ok1 = accept_nb(g1, s10x, s10y, dn1), ok2 = accept_nb(g2, s10x, s10y, dn2) && two;
             // Both accepted (the ray enters through one chord and leaves through the other): the distance is monotone
