@@ -14,8 +14,10 @@ The reference delegates this to the absent third-party `rvo2` module, so the ora
 (parity unpinned for the ORCA arithmetic); this file pins neighbour half-planes (App. A.4) and the
 feasible linear programme (App. A.5 LP1 / LP2) to the paper's geometry on thousands of random configurations, and the main
 branch of the obstacle half-plane (A.3) on random free-standing walls, and the infeasible case (A.5 LP3) to the paper's
-"smallest largest penetration" on hemmed-in agents.  The convexity / foreign-leg / already-covered rules of A.3 and the
-obstacle lines as hard constraints inside LP3 stay with the analytic cases of test_oracle_orca.py.
+"smallest largest penetration" on hemmed-in agents.  The convexity / foreign-leg / already-covered rules of A.3 are held
+to the PURPOSE of the obstacle half-planes -- the chosen velocity keeps the agent clear of the polygon for tau seconds --
+on convex polygons, an L-shaped one and a room; obstacle lines as hard constraints inside LP3 stay with the analytic cases
+of test_oracle_orca.py.
 """
 import numpy as np
 import pytest
@@ -397,3 +399,80 @@ def test_infeasible_case_minimises_the_largest_penetration():
         assert np.linalg.norm(got - vbest) < (1e-4 if sharp else 2e-3), (got, vbest, gap)
         checked += 1
     assert checked >= 700, checked
+
+
+def _seg_seg_dist(p1, q1, p2, q2):
+    """distance between the segments [p1, q1] and [p2, q2] (they do not cross here, or the distance is 0)"""
+    def pt_seg(p, a, b):
+        ab = b - a
+        t = 0.0 if ab @ ab == 0 else np.clip((p - a) @ ab / (ab @ ab), 0.0, 1.0)
+        return np.linalg.norm(p - (a + t * ab))
+    def cross(u, v):
+        return u[0] * v[1] - u[1] * v[0]
+    d1, d2 = q1 - p1, q2 - p2
+    den = cross(d1, d2)
+    if abs(den) > 1e-15:
+        t = cross(p2 - p1, d2) / den; u = cross(p2 - p1, d1) / den
+        if 0.0 <= t <= 1.0 and 0.0 <= u <= 1.0:
+            return 0.0
+    return min(pt_seg(p1, p2, q2), pt_seg(q1, p2, q2), pt_seg(p2, p1, q1), pt_seg(q2, p1, q1))
+
+
+@pytest.mark.parametrize("shape", ["convex", "L", "room"])
+def test_polygon_obstacles_new_velocity_is_collision_free_for_tau(shape):
+    """App. A.3 as a whole (corners, the convexity flags, legs taken over from the neighbouring edge, edges already covered
+    by an earlier line) against the definition of what the obstacle half-planes are for: a velocity that satisfies them lies
+    outside VO^tau of every edge, i.e. an agent that keeps it does not come within its radius of the polygon for tau seconds
+    (the agent takes the whole responsibility towards an obstacle: the half-plane is tangent to VO, not halfway).  A lone
+    agent next to a convex polygon, in the notch of an L-shaped one, and inside a room (a clockwise boundary)."""
+    rng = np.random.RandomState({"convex": 21, "L": 22, "room": 23}[shape])
+    checked = active = 0
+    worst = np.inf
+    for _ in range(900):
+        if shape == "convex":
+            m = rng.randint(3, 7)
+            ang = np.sort(rng.uniform(0, 2 * np.pi, m))
+            if np.min(np.diff(np.concatenate([ang, [ang[0] + 2 * np.pi]]))) < 0.5:
+                continue
+            rad = rng.uniform(0.8, 2.0)
+            poly = np.stack([np.cos(ang), np.sin(ang)], 1) * rad                          # counterclockwise: an obstacle
+            pa = rng.uniform(0, 2 * np.pi)
+            pos = rng.uniform(0.5 * rad + 0.6, rad + 2.0) * np.array([np.cos(pa), np.sin(pa)])
+        elif shape == "L":
+            s_ = rng.uniform(1.5, 2.5)
+            poly = np.array([[0, 0], [2 * s_, 0], [2 * s_, s_], [s_, s_], [s_, 2 * s_], [0, 2 * s_]], np.float64)  # ccw
+            pos = np.array([s_, s_]) + rng.uniform(0.3, 2.2, 2) * (1 if rng.rand() < 0.7 else -1)
+            if rng.rand() < 0.3:
+                pos = rng.uniform(-2, 2 * s_ + 2, 2)
+        else:
+            w, h = rng.uniform(3, 6, 2)
+            poly = np.array([[0, 0], [0, h], [w, h], [w, 0]], np.float64)                  # clockwise: agents live inside
+            pos = np.array([rng.uniform(0.6, w - 0.6), rng.uniform(0.6, h - 0.6)])
+        edges = [(poly[k], poly[(k + 1) % len(poly)]) for k in range(len(poly))]
+        d0 = min(_seg_seg_dist(pos, pos, a, b) for a, b in edges)
+        # outside the obstacle (or inside the room) with some air: crossing number of a ray to the right
+        cn = sum(1 for a, b in edges if (a[1] > pos[1]) != (b[1] > pos[1]) and
+                 pos[0] < a[0] + (pos[1] - a[1]) * (b[0] - a[0]) / (b[1] - a[1]))
+        if d0 < R + 0.05 or (cn % 2 == 1) != (shape == "room"):
+            continue
+        sp, va = rng.uniform(0.0, 1.0), rng.uniform(0, 2 * np.pi)
+        vel = sp * np.array([np.cos(va), np.sin(va)])
+        ctr = poly.mean(0) if shape != "room" else pos + rng.uniform(-1, 1, 2)
+        aim = ctr - pos if shape != "room" else np.array([np.cos(va), np.sin(va)])
+        pref = rng.uniform(0.5, 1.0) * aim / max(1e-9, np.linalg.norm(aim)) + rng.uniform(-0.3, 0.3, 2)
+        s = PyRVOSimulator(timeStep=DT, neighborDist=5.0, maxNeighbors=0, timeHorizon=TAU, timeHorizonObst=TAU, radius=R,
+                           maxSpeed=VMAX)
+        s.addAgent(tuple(map(float, pos)))
+        s.addObstacle([tuple(map(float, v)) for v in poly]); s.processObstacles()
+        s.setAgentVelocity(0, tuple(map(float, vel))); s.setAgentPrefVelocity(0, tuple(map(float, pref)))
+        s.doStep()
+        got = np.array(s.getAgentVelocity(0), np.float64)
+        p32 = np.array(pos, np.float32).astype(np.float64)
+        clearance = min(_seg_seg_dist(p32, p32 + TAU * got, a, b) for a, b in edges)
+        worst = min(worst, clearance - R)
+        assert clearance > R - 5e-6, (shape, poly, pos, vel, pref, got, clearance)   # observed worst: r - 3.1e-7
+        checked += 1
+        pr = np.array(pref, np.float32).astype(np.float64)
+        prc = pr / max(1.0, np.linalg.norm(pr) / VMAX)
+        active += int(np.linalg.norm(got - prc) > 1e-4)      # the polygon actually constrained the choice
+    assert checked >= 150 and active >= 60, (shape, checked, active)
