@@ -329,6 +329,7 @@ static hipError_t launch_obs(ca_env* e) {
     o.bpa = (o.N + apb - 1) / apb;
     o.paircap = 16 * (e->K + e->S);
     o.a0 = 0; o.dbg = e->dbg_obs;
+    o.xcd = o.A % 8 == 0 ? 1 : 0;  // the arena's observation on the XCD (workgroup index mod 8) whose solve workgroup wrote its state
     o.radius = e->cfg.radius;
     memcpy(o.rays, e->rays, sizeof o.rays);
     memcpy(o.oct, e->oct, sizeof o.oct);

@@ -33,6 +33,7 @@ struct ObsArgs {
     int A, N, K, S, bpa;  // bpa = workgroups per arena = ceil(N / 16)
     int paircap;          // entries of an agent's (source, ray) pair list: 16 rays x (K + S) sources
     int a0;               // first arena of this launch
+    int xcd;              // 1: workgroup b serves an arena with (arena - a0) % 8 == b % 8, i.e. on the XCD whose solve wave wrote it
     unsigned long long* dbg;  // CA_STAMPS diagnostic build only: [waves][16] phase time stamps
     float radius;         // of the octagon = agent radius (env.py:31,338)
     float rays[32];       // env.py:321-332
@@ -111,9 +112,14 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     const int g = tid >> 4, r = tid & 15;
     const int N = p.N, K = p.K, S = p.S;
     const int PAIRCAP = p.paircap;
-    const int ab = blockIdx.x / p.bpa;
+    // Workgroups go round the 8 XCDs by index, and an arena's state was written by solve workgroup `arena` (one arena per
+    // solve workgroup from 16 agents up): its observation workgroups take indices of the same residue, so that what they
+    // read sits in that XCD's L2 (C3: obs_kernel 62.2 -> 61.5 us).
+    int bid = blockIdx.x;
+    if (p.xcd) { const int x = bid & 7, idx = bid >> 3, q8 = idx / p.bpa; bid = (x + 8 * q8) * p.bpa + (idx - q8 * p.bpa); }
+    const int ab = bid / p.bpa;
     const int a = p.a0 + ab;
-    const int i = (blockIdx.x - ab * p.bpa) * OBS_APB + g;
+    const int i = (bid - ab * p.bpa) * OBS_APB + g;
     const bool active = i < N;
     const size_t q = (size_t)a * N + (active ? i : 0);
     const ObstDev* tab = p.obst + (p.tab_off ? p.tab_off[a] : 0);  // this arena's edge table
