@@ -11,7 +11,8 @@
 //     few hundred waves): candidates, edges, lines and LP1 clips are dealt over the quad and merged with DPP moves;
 //     one launch can advance T ORCA-only steps with the arena resident in registers / LDS (ca_rollout).
 //   * obs_kernel (ca_obs.h): 16 lanes per agent, one lane per (source, ray) pair, ds_min_u64 merge per ray.
-// Arenas are independent, so there is no inter-workgroup traffic and no XCD affinity to exploit: the grid is arena-major.
+// Arenas are independent, so there is no inter-workgroup traffic; the grids are arena-major, and the observation workgroups of
+// an arena are indexed so that they run on the XCD whose solve workgroup wrote the arena's state (ca_obs.h).
 // Diagnostics: the CA_STAMPS build (tools/stamps.py, tools/diag/placement.py; never the product library) adds phase
 // time stamps, a block order for the solve kernel and the two ca_debug_* entry points that read / install them.
 // ca_nbr.h claims 128 VGPRs for the stand-alone neighbour kernel on purpose (four waves per SIMD, see there).

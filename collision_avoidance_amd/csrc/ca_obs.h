@@ -406,7 +406,12 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         if (!(bx == 0.0f && by == 0.0f)) { vx = wx; vy = wy; }  // utils.py:103
     }
     CA_OSTAMP(7);
-    reinterpret_cast<float4*>(p.obs)[q * 16 + r] = make_float4(bx, by, vx, vy);
+    {   // written once, read by the caller: a non-temporal store, so that the 67 MB of a C3 step do not push the arenas'
+        // state out of the L2 that the next solve reads it from
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f out = {bx, by, vx, vy};
+        __builtin_nontemporal_store(out, reinterpret_cast<v4f*>(p.obs) + (q * 16 + r));
+    }
     CA_OSTAMP(8);
 }
 
