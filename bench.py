@@ -251,10 +251,11 @@ def main():
         warm_run += 50 * chunk
         torch.cuda.synchronize()
     env.reset_stats()
-    # the kernel launches of every 8th step (short runs: every (steps // 8)-th) of the timed region are bracketed by HIP events on the
-    # stream they run on (recorded inside the library, which is where the launches are issued);
-    # sampling keeps the event records from stretching the timed region (every launch: +5 % wall)
-    env.profile(1 if steps_per_launch > 1 else max(1, min(8, args.steps // 8)))  # a short run (the driver's --steps 20) still brackets >= 8 steps
+    # the kernel launches of every 8th step (short runs: every (steps // 5)-th) of the timed region carry a start and a stop
+    # event on their own dispatch (hipExtLaunchKernel inside the library, on the stream the kernels run on).  A sampled
+    # step still costs ~10 us of dispatch serialisation, so sampling every step would stretch the timed region by 8 %;
+    # the driver's --steps 20 brackets 5 steps (2 % of its region), the default run 250.
+    env.profile(1 if steps_per_launch > 1 else max(1, min(8, args.steps // 5)))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -4,6 +4,7 @@
 #include "../../include/ca_env.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -103,19 +104,27 @@ static hipEvent_t prof_event(ca_env* e) {
     if (hipEventCreate(&ev) != hipSuccess) return nullptr;
     return ev;
 }
-struct ProfScope {  // records an event before and after the launches issued while it is alive
-    ca_env* e; hipEvent_t t0 = nullptr; int kind;
+// Kernel times: a sampled launch carries a start and a stop event ON ITS OWN DISPATCH (hipExtLaunchKernel: the
+// timestamps of the dispatch packet's completion signal), not events recorded around it in the stream -- a recorded event
+// is a barrier packet of its own and costs the step loop ~2.5 us each, 4 % of a C3 step when every second step is sampled.
+struct ProfScope {
+    ca_env* e; hipEvent_t t0 = nullptr, t1 = nullptr; int kind;
     ProfScope(ca_env* env, int k) : e(env), kind(k) {
-        if (e->profiling && (t0 = prof_event(e))) hipEventRecord(t0, e->stream);
+        if (!e->profiling) return;
+        t0 = prof_event(e);
+        t1 = t0 ? prof_event(e) : nullptr;
+        if (t0 && !t1) { e->free_events.push_back(t0); t0 = nullptr; }
     }
     ~ProfScope() {
-        if (!t0) return;
-        hipEvent_t t1 = prof_event(e);
-        if (!t1) { e->free_events.push_back(t0); return; }
-        hipEventRecord(t1, e->stream);
-        e->spans.push_back({t0, t1, kind});
+        if (t0) e->spans.push_back({t0, t1, kind});
     }
 };
+template <class... Args>
+static void launch_k(const ProfScope& ps, void (*kernel)(Args...), dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                     Args... args) {
+    if (ps.t0) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, ps.t0, ps.t1, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+}
 
 static size_t AN(const ca_env* e) { return (size_t)e->cfg.n_arenas * e->cfg.n_agents; }
 
@@ -218,11 +227,11 @@ static void launch_nbr_k(ca_env* e, const StepArgs& a) {
     const dim3 grid(e->grid_n), block(e->BSn);
     ProfScope ps(e, KIND_NBR);
     switch (e->BSn) {
-        case 64: hipLaunchKernelGGL((nbr_kernel<KMAX, 64, SM>), grid, block, 0, e->stream, a); break;
-        case 128: hipLaunchKernelGGL((nbr_kernel<KMAX, 128, SM>), grid, block, 0, e->stream, a); break;
-        case 256: hipLaunchKernelGGL((nbr_kernel<KMAX, 256, SM>), grid, block, 0, e->stream, a); break;
-        case 512: hipLaunchKernelGGL((nbr_kernel<KMAX, 512, SM>), grid, block, 0, e->stream, a); break;
-        default: hipLaunchKernelGGL((nbr_kernel<KMAX, 1024, SM>), grid, block, 0, e->stream, a); break;
+        case 64: launch_k(ps, nbr_kernel<KMAX, 64, SM>, grid, block, 0, e->stream, a); break;
+        case 128: launch_k(ps, nbr_kernel<KMAX, 128, SM>, grid, block, 0, e->stream, a); break;
+        case 256: launch_k(ps, nbr_kernel<KMAX, 256, SM>, grid, block, 0, e->stream, a); break;
+        case 512: launch_k(ps, nbr_kernel<KMAX, 512, SM>, grid, block, 0, e->stream, a); break;
+        default: launch_k(ps, nbr_kernel<KMAX, 1024, SM>, grid, block, 0, e->stream, a); break;
     }
 }
 template <int KMAX, int ST, bool FUSE>
@@ -232,17 +241,17 @@ static hipError_t launch_step_kf(ca_env* e, const StepArgs& a) {
     ProfScope ps(e, KIND_STEP);
     if constexpr (FUSE && ST > 0) {
         if (e->help) {  // twice the lanes: the upper half helps in the neighbour scan of its arena and ends (ca_nbr.h)
-            if (e->BS == 256) hipLaunchKernelGGL((step_kernel<KMAX, 256, ST, true, 2>), grid, dim3(512), e->lds, e->stream, a);
-            else hipLaunchKernelGGL((step_kernel<KMAX, 512, ST, true, 2>), grid, dim3(1024), e->lds, e->stream, a);
+            if (e->BS == 256) launch_k(ps, step_kernel<KMAX, 256, ST, true, 2>, grid, dim3(512), e->lds, e->stream, a);
+            else launch_k(ps, step_kernel<KMAX, 512, ST, true, 2>, grid, dim3(1024), e->lds, e->stream, a);
             return hipGetLastError();
         }
     }
     switch (e->BS) {  // (neighbour search +) lines + LP + integration + reward/done
-        case 64: hipLaunchKernelGGL((step_kernel<KMAX, 64, ST, FUSE>), grid, block, e->lds, e->stream, a); break;
-        case 128: hipLaunchKernelGGL((step_kernel<KMAX, 128, ST, FUSE>), grid, block, e->lds, e->stream, a); break;
-        case 256: hipLaunchKernelGGL((step_kernel<KMAX, 256, ST, FUSE>), grid, block, e->lds, e->stream, a); break;
-        case 512: hipLaunchKernelGGL((step_kernel<KMAX, 512, ST, FUSE>), grid, block, e->lds, e->stream, a); break;
-        default: hipLaunchKernelGGL((step_kernel<KMAX, 1024, ST, FUSE>), grid, block, e->lds, e->stream, a); break;
+        case 64: launch_k(ps, step_kernel<KMAX, 64, ST, FUSE>, grid, block, e->lds, e->stream, a); break;
+        case 128: launch_k(ps, step_kernel<KMAX, 128, ST, FUSE>, grid, block, e->lds, e->stream, a); break;
+        case 256: launch_k(ps, step_kernel<KMAX, 256, ST, FUSE>, grid, block, e->lds, e->stream, a); break;
+        case 512: launch_k(ps, step_kernel<KMAX, 512, ST, FUSE>, grid, block, e->lds, e->stream, a); break;
+        default: launch_k(ps, step_kernel<KMAX, 1024, ST, FUSE>, grid, block, e->lds, e->stream, a); break;
     }
     return hipGetLastError();
 }
@@ -268,6 +277,7 @@ static hipError_t launch_quad(ca_env* e, const StepArgs& a) {
     ProfScope ps(e, KIND_STEP);
     StepArgs arg = a;
     void* params[] = {&arg};
+    if (ps.t0) return hipExtLaunchKernel(quad_fn(e), dim3(e->grid_q), dim3(e->BSq), params, e->lds_q, e->stream, ps.t0, ps.t1, 0);
     return hipLaunchKernel(quad_fn(e), dim3(e->grid_q), dim3(e->BSq), params, e->lds_q, e->stream);
 }
 static hipError_t launch_step(ca_env* e, const StepArgs& a) {
@@ -336,7 +346,7 @@ static hipError_t launch_obs(ca_env* e) {
     const dim3 grid((unsigned)((size_t)o.A * o.bpa)), block(obs_bs);
     const size_t lds = obs_lds_bytes(o.N, obs_bs, o.paircap);
     ProfScope ps(e, KIND_OBS);
-    hipLaunchKernelGGL(obs_fn(obs_bs, e->nidx16 != 0), grid, block, lds, e->stream, o);
+    launch_k(ps, obs_fn(obs_bs, e->nidx16 != 0), grid, block, lds, e->stream, o);
     return hipGetLastError();
 }
 
@@ -1250,6 +1260,14 @@ int ca_profile(ca_env* e, int32_t period) {
     if (!e || period < 0) return fail(e, CA_EINVAL, "ca_profile: bad argument");
     e->prof_period = period;
     e->profiling = period == 1;
+    if (period > 0) {  // the events of the first sampled steps exist before the caller's timed region starts
+        HIPCHK(e, hipSetDevice(e->device));
+        while (e->free_events.size() < 256) {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreate(&ev) != hipSuccess) break;
+            e->free_events.push_back(ev);
+        }
+    }
     return CA_OK;
 }
 
