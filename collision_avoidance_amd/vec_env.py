@@ -202,7 +202,7 @@ class VecCollisionAvoidanceEnv:
         self._call("ca_reset_stats", self.h)
 
     def profile(self, period=1):
-        """Bracket the kernel launches of every `period`-th step with HIP events (0 = off)."""
+        """Time the kernel launches of every `period`-th step (start / stop events on the dispatch itself; 0 = off)."""
         self._call("ca_profile", self.h, int(period))
 
     def profile_read(self):

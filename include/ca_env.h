@@ -237,12 +237,13 @@ int ca_sync(ca_env* env);
  * Host pointers. */
 int ca_debug_math(ca_env* env, int32_t op, const void* in, void* out, int32_t n);
 
-/* Per-kernel timing for roofline reports.  ca_profile(env, k), k >= 1, brackets the kernel launches
- * of every k-th step of this handle with pairs of HIP events on the handle's stream (k = 1: every
- * launch); ca_profile_read synchronises and returns, per kernel kind, the number of sampled launches
- * and their mean duration in milliseconds since the last read (kinds: 0 nbr_kernel -- only when the neighbour search runs as a launch
- * of its own, CA_FUSE_NBR=0; normally it is the head of step_kernel --, 1 step_kernel,
- * 2 obs_kernel, 3 reset kernels), then clears them.  ca_profile(env, 0) switches it off (default). */
+/* Per-kernel timing for roofline reports.  ca_profile(env, k), k >= 1: every kernel launch of every k-th step of this
+ * handle carries a start and a stop HIP event on its own dispatch (hipExtLaunchKernel on the handle's stream: the execution
+ * time of the kernel, what rocprofv3 --kernel-trace reports; k = 1: every launch).  ca_profile_read synchronises and
+ * returns, per kernel kind, the number of sampled launches and their mean duration in milliseconds since the last read
+ * (kinds: 0 nbr_kernel -- only when the neighbour search runs as a launch of its own, CA_FUSE_NBR=0; normally it is the
+ * head of step_kernel --, 1 step_kernel, 2 obs_kernel, 3 reset kernels), then clears them.  ca_profile(env, 0) switches
+ * it off (default).  A sampled step costs ~10 us of dispatch serialisation; results never depend on it. */
 int ca_profile(ca_env* env, int32_t period);
 int ca_profile_read(ca_env* env, int32_t counts[4], float mean_ms[4]);
 
