@@ -13,7 +13,8 @@ state and actions resident in HBM.  value = agents advanced per second over all 
 N > 1: one rank per GPU (torch.distributed.run; when this script is started directly with --gpus N it
 starts the N ranks itself, as a child process, before anything touches the GPU, and relays rank 0's line);
 arenas are sharded (no data-path collective: arenas never interact), ONE RCCL all_gather of the per-rank
-statistics at the end.
+record at the end (statistics + the rank's time for the timed region, so the maximum over ranks needs no collective of
+its own); the only other synchronisation is the barrier on either side of the timed region that the benchmark contract asks for.
 """
 import argparse
 import json
@@ -161,7 +162,7 @@ def counters_for(workload, mode, variant, starts, kernels):
     otherwise null with the reason, so a changed kernel can never carry stale counter data."""
     import glob
     from collision_avoidance_amd import build as _b
-    sha = _b.source_sha()
+    sha = _b.loaded_sha()   # the hash compiled into the library that ran
     tag = "%s_%s" % (workload, mode) + ("" if variant == "walls" else "_free") + ("" if starts == "overlap" else "_separated")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters_%s.json" % tag)))
     if not files:
@@ -268,22 +269,29 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     ktimes = env.profile_read()
     env.profile(0)
     st = env.stats()
+    per_step_calls = None
+    if not full and chunk > 1:   # the same ORCA-only workload through one ca_orca_step call per step, for comparison
+        torch.cuda.synchronize()
+        n2 = max(chunk, min(args.steps, 500))
+        t1 = time.perf_counter()
+        for i in range(n2):
+            env._call("ca_orca_step", env.h, _lib.F_STATS)
+        torch.cuda.synchronize()
+        per_step_calls = A * N * n2 / (time.perf_counter() - t1)
 
-    # the single data collective of the job: per-rank statistics (RCCL all_gather over xGMI when N > 1)
-    per_rank_stats, total_stats = cad.gather_stats(st, device=coll_dev, extra={"device": local})
+    # THE collective of the job: one all_gather of the per-rank record -- statistics, device, and the rank's own time for the
+    # timed region in nanoseconds (RCCL over xGMI when N > 1); the job's time is the maximum over the gathered records
+    per_rank_stats, total_stats = cad.gather_stats(st, device=coll_dev, extra={"device": local, "dt_ns": int(dt * 1e9)})
+    dt = max(d["dt_ns"] for d in per_rank_stats) * 1e-9
     if rank == 0:
         agents = A * N
         value = world * agents * args.steps / dt
         kbytes_of = {"nbr_kernel": 0, "step_kernel": BYTES_STEP_KERNEL_FULL if full else BYTES_STEP_KERNEL_ORCA,
                      "obs_kernel": BYTES_OBS_KERNEL}
-        kms_of = {k: v[1] / (steps_per_launch if k == "step_kernel" else 1) for k, v in ktimes.items() if v[0] > 0 and k in kbytes_of}
+        kms_of = {k: v[1] for k, v in ktimes.items() if v[0] > 0 and k in kbytes_of}   # (a T-step launch is reported per step)
         # dominant kernel: strictly the longest average launch (no tie-break)
         dom = max(kms_of, key=lambda k: kms_of[k])
         kms, kbytes = kms_of[dom], kbytes_of[dom]
@@ -293,11 +301,14 @@ def main():
                           "frac": agents * kbytes_of[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS}
                       for k, v in kms_of.items()}
         cj, csrc = counters_for(args.workload, args.mode, args.variant, args.starts, kms_of)
-        traffic, traffic_detail, valu = None, {"source": csrc}, None
+        traffic, traffic_low, traffic_high, traffic_detail, valu = None, None, None, {"source": csrc}, None
         if cj is not None:
             kk = cj.get("kernels", {})
             if dom in kk and "hbm_bytes_high" in kk[dom]:
-                traffic = kk[dom]["hbm_bytes_high"]
+                # FETCH_SIZE on gfx950 tallies the 128-B requests of wide reads at 64 B: the true figure lies between the
+                # reported one (low) and the one with FETCH doubled (high); `traffic` quotes the conservative high end
+                traffic_low, traffic_high = kk[dom].get("hbm_bytes_low"), kk[dom]["hbm_bytes_high"]
+                traffic = traffic_high
             traffic_detail = {"source": csrc, "src_sha": cj.get("src_sha"),
                               "per_kernel": {k: {x: kk[k].get(x) for x in ("FETCH_SIZE_KB", "WRITE_SIZE_KB", "hbm_bytes_low",
                                                                            "hbm_bytes_high", "algorithmic_bytes")}
@@ -357,6 +368,10 @@ def main():
                       for r, d in enumerate(per_rank_stats)],
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_low": traffic_low, "traffic_high": traffic_high,
+                         # what the counters say really limits the kernel: vector-instruction issue (see `valu`:
+                         # frac_of_issue_bound), not HBM -- the HBM fraction above is reported because the metric asks for it
+                         "limited_by": "valu-issue",
                          "algorithmic_bytes_per_agent": kbytes, "kernel_ms": kms, "per_kernel": per_kernel,
                          "traffic_detail": traffic_detail},
             "valu": valu,
@@ -367,8 +382,17 @@ def main():
                                       "frac": agents * (316 if full else 52) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
             "stats": {k: total_stats[k] for k in cad.STAT_KEYS},
             "launch": env.launch_info(),
-            "src_sha": _b.source_sha(),
+            "src_sha": _b.loaded_sha(),      # compiled into the library that ran (ca_source_sha)
+            "src_sha_on_disk": _b.source_sha(),
+            "backend": backend if world > 1 else None,
+            "collectives": {"data_path": 0, "job": "one all_gather of the per-rank record (statistics, device, dt)",
+                            "timing_barriers": 2 if world > 1 else 0},
         }
+        if per_step_calls is not None:
+            out["orca_per_step_calls"] = {"value": world * per_step_calls, "unit": "agent-steps/s",
+                                          "note": "same workload, one ca_orca_step call (= one launch) per step; rank 0's rate x world"}
+        # agent_steps is counted IN the solve kernels (per arena, the steps it was advanced): a launch that did not run, or
+        # skipped arenas, shows here
         if sum(d["agent_steps"] for d in per_rank_stats) != world * agents * args.steps:
             raise SystemExit("bench.py: the ranks report %d agent-steps, expected %d" %
                              (sum(d["agent_steps"] for d in per_rank_stats), world * agents * args.steps))

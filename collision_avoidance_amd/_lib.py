@@ -23,7 +23,7 @@ EXPORTS = ("ca_create", "ca_destroy", "ca_last_error", "ca_set_stream", "ca_set_
            "ca_get", "ca_field_ptr", "ca_bind_obs", "ca_reset", "ca_step", "ca_step_host", "ca_orca_step", "ca_observe", "ca_rollout",
            "ca_get_stats", "ca_reset_stats", "ca_sync", "ca_debug_math", "ca_profile", "ca_profile_read", "ca_launch_info",
            "ca_alan_configure", "ca_alan_step", "ca_alan_rollout", "ca_reset_masked", "ca_get_obstacles",
-           "ca_set_obstacles_per_arena", "ca_get_obstacles_arena", "ca_solver_info")
+           "ca_set_obstacles_per_arena", "ca_get_obstacles_arena", "ca_solver_info", "ca_source_sha")
 
 
 class Config(C.Structure):
@@ -101,8 +101,10 @@ def load():
     L.ca_profile_read.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_float)]
     L.ca_launch_info.argtypes = [vp] + [C.POINTER(i32)] * 4
     L.ca_solver_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.ca_source_sha.argtypes = []
+    L.ca_source_sha.restype = C.c_char_p
     for name in EXPORTS:
-        if name != "ca_last_error":
+        if name not in ("ca_last_error", "ca_source_sha"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -31,6 +31,15 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
+def loaded_sha():
+    """The source hash compiled into the library that is actually loaded (ca_source_sha)."""
+    import ctypes
+    from . import _lib
+    L = _lib.load()
+    L.ca_source_sha.restype = ctypes.c_char_p
+    return L.ca_source_sha().decode()
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -49,7 +58,9 @@ def build(force=False, verbose=False):
     """Compile the HIP library if it is missing or older than its sources; returns its path."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH, SOURCES[0]]
+    # the hash of what is being compiled goes INTO the library (ca_source_sha()): a bench line or a counter profile
+    # then names the sources of the code that ran, not of whatever lies on disk next to it
+    cmd = [hipcc()] + HIPCC_FLAGS + ['-DCA_SRC_SHA="%s"' % source_sha(), "-o", LIB_PATH, SOURCES[0]]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

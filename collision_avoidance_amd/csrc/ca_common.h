@@ -39,6 +39,8 @@ struct StepCold {
     int *agent_done, *arrive_step, *regoal_count;
     int *step_count, *arena_done, *episode;
     unsigned long long* arena_stats;  // [A][8]
+    unsigned long long* arena_steps;  // [A] steps this arena was ADVANCED by a solve kernel (counted in the kernel by the
+                                      // arena's owner lane: the evidence of work behind ca_stats.agent_steps)
     double reward_scale;
     uint64_t seed;
     int64_t arena_offset;

@@ -39,6 +39,7 @@ struct ca_env {
     size_t cvt_cap = 0;
     int *step_count = nullptr, *arena_done = nullptr, *episode = nullptr;
     unsigned long long* arena_stats = nullptr;
+    unsigned long long* arena_steps = nullptr;  // [A] steps each arena was advanced, counted by the solve kernels
     float* obs = nullptr;
     bool obs_external = false;
     unsigned long long* dbg = nullptr;  // CA_STAMPS diagnostic build only
@@ -68,12 +69,12 @@ struct ca_env {
     int BSq = 64, grid_q = 1, SQ = 4;   // SQ: obstacle-neighbour capacity of the quad variant (4 or 16)
     size_t lds_q = 0;
     size_t lds = 0;
-    uint64_t steps_done = 0;  // env steps executed (agent_steps = steps_done * A * N)
+    uint64_t steps_done = 0;  // env steps enqueued (profiling cadence only: ca_stats.agent_steps is counted in the kernels)
     float rays[32], oct[32];
     // opt-in per-kernel timing (ca_profile): event pairs recorded around launches, drained on read
     bool profiling = false;   // events are recorded for the current step
     int prof_period = 0;      // 0 = off, k = every k-th step
-    struct Span { hipEvent_t t0, t1; int kind; };
+    struct Span { hipEvent_t t0, t1; int kind; int steps; };  // steps: env steps advanced by the timed launch (ca_rollout: T)
     std::vector<Span> spans;
     std::vector<hipEvent_t> free_events;
     std::string err;
@@ -97,7 +98,8 @@ static int fail(ca_env* e, int code, const char* fmt, ...) {
         if (_r != hipSuccess) return fail(e, CA_EHIP, "%s failed: %s", #call, hipGetErrorString(_r)); \
     } while (0)
 
-enum { KIND_NBR = 0, KIND_STEP = 1, KIND_OBS = 2, KIND_RESET = 3 };  // KIND_RESET also times the small ALAN kernels
+enum { KIND_NBR = 0, KIND_STEP = 1, KIND_OBS = 2, KIND_RESET = 3 };
+enum { CA_ROLLOUT_MAX_T = 256 };  // steps per launch of the one-launch rollout (ca_rollout)  // KIND_RESET also times the small ALAN kernels
 static hipEvent_t prof_event(ca_env* e) {
     if (!e->free_events.empty()) { hipEvent_t ev = e->free_events.back(); e->free_events.pop_back(); return ev; }
     hipEvent_t ev = nullptr;
@@ -108,15 +110,15 @@ static hipEvent_t prof_event(ca_env* e) {
 // timestamps of the dispatch packet's completion signal), not events recorded around it in the stream -- a recorded event
 // is a barrier packet of its own and costs the step loop ~2.5 us each, 4 % of a C3 step when every second step is sampled.
 struct ProfScope {
-    ca_env* e; hipEvent_t t0 = nullptr, t1 = nullptr; int kind;
-    ProfScope(ca_env* env, int k) : e(env), kind(k) {
+    ca_env* e; hipEvent_t t0 = nullptr, t1 = nullptr; int kind; int steps;
+    ProfScope(ca_env* env, int k, int n_steps = 1) : e(env), kind(k), steps(n_steps) {
         if (!e->profiling) return;
         t0 = prof_event(e);
         t1 = t0 ? prof_event(e) : nullptr;
         if (t0 && !t1) { e->free_events.push_back(t0); t0 = nullptr; }
     }
     ~ProfScope() {
-        if (t0) e->spans.push_back({t0, t1, kind});
+        if (t0) e->spans.push_back({t0, t1, kind, steps});
     }
 };
 template <class... Args>
@@ -198,7 +200,7 @@ static void fill_cold(const ca_env* e, StepCold& c) {
     c.orient_x = e->orient_x; c.orient_y = e->orient_y;
     c.agent_done = e->agent_done; c.arrive_step = e->arrive_step; c.regoal_count = e->regoal_count;
     c.step_count = e->step_count; c.arena_done = e->arena_done; c.episode = e->episode;
-    c.arena_stats = e->arena_stats;
+    c.arena_stats = e->arena_stats; c.arena_steps = e->arena_steps;
     c.reward_scale = g.reward_scale; c.seed = g.seed; c.arena_offset = g.arena_offset;
     c.max_step = g.max_step; c.done_mode = g.done_mode; c.done_x_thresh = g.done_x_thresh;
     c.spawn_x0 = g.spawn_x0; c.spawn_x1 = g.spawn_x1; c.spawn_y0 = g.spawn_y0; c.spawn_y1 = g.spawn_y1;
@@ -274,7 +276,7 @@ static const void* quad_fn(const ca_env* e) {
 }
 // neighbour search + lines + LP + integration + reward/done, four lanes per agent, a.T steps
 static hipError_t launch_quad(ca_env* e, const StepArgs& a) {
-    ProfScope ps(e, KIND_STEP);
+    ProfScope ps(e, KIND_STEP, a.T > 1 ? a.T : 1);
     StepArgs arg = a;
     void* params[] = {&arg};
     if (ps.t0) return hipExtLaunchKernel(quad_fn(e), dim3(e->grid_q), dim3(e->BSq), params, e->lds_q, e->stream, ps.t0, ps.t1, 0);
@@ -347,6 +349,22 @@ static hipError_t launch_obs(ca_env* e) {
     const size_t lds = obs_lds_bytes(o.N, obs_bs, o.paircap);
     ProfScope ps(e, KIND_OBS);
     launch_k(ps, obs_fn(obs_bs, e->nidx16 != 0), grid, block, lds, e->stream, o);
+    return hipGetLastError();
+}
+
+// reset_kernel + reset_arena_kernel, each timed on its own dispatch (kind 3) when the step is sampled
+static hipError_t launch_reset(ca_env* e, const StepArgs& a) {
+    const unsigned an = (unsigned)AN(e);
+    {
+        ProfScope ps(e, KIND_RESET);
+        launch_k(ps, reset_kernel, dim3((an + 255) / 256), dim3(256), 0, e->stream, a);
+    }
+    hipError_t r = hipGetLastError();
+    if (r != hipSuccess) return r;
+    {
+        ProfScope ps(e, KIND_RESET);
+        launch_k(ps, reset_arena_kernel, dim3((e->cfg.n_arenas + 255) / 256), dim3(256), 0, e->stream, a);
+    }
     return hipGetLastError();
 }
 
@@ -546,6 +564,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     if (r == hipSuccess) r = dalloc(e, &e->arena_done, A);
     if (r == hipSuccess) r = dalloc(e, &e->episode, A);
     if (r == hipSuccess) r = dalloc(e, &e->arena_stats, A * ST_STRIDE);
+    if (r == hipSuccess) r = dalloc(e, &e->arena_steps, A);
     if (r == hipSuccess) r = dalloc(e, &e->obs, an * CA_OBS_DIM);
     if (r == hipSuccess) r = dalloc(e, &e->d_obst, (size_t)1);
 #ifdef CA_STAMPS
@@ -599,7 +618,7 @@ int ca_destroy(ca_env* e) {
                     e->goal2_x, e->goal2_y, e->reward, e->tmp_x, e->tmp_y, e->orient_x, e->orient_y,
                     e->agent_done, e->arrive_step,
                     e->regoal_count, e->counts, e->nb_idx, e->obst_idx, e->cvt_buf, e->d_tab_off, e->d_cold, e->d_order, e->step_count,
-                    e->arena_done, e->episode, e->arena_stats, e->d_obst, e->dbg, e->dbg_obs,
+                    e->arena_done, e->episode, e->arena_stats, e->arena_steps, e->d_obst, e->dbg, e->dbg_obs,
                     e->alan_w, e->alan_t, e->alan_dirs, e->alan_u, e->alan_action, e->mask_buf};
     for (void* b : bufs) if (b) hipFree(b);
     if (e->obs && !e->obs_external) hipFree(e->obs);
@@ -985,13 +1004,7 @@ int ca_reset(ca_env* e, const float* pos_x, const float* pos_y, int32_t pos_is_d
             a.reset_px = e->tmp_x; a.reset_py = e->tmp_y;
         }
     }
-    const unsigned an = (unsigned)AN(e);
-    {
-    ProfScope ps(e, KIND_RESET);
-    hipLaunchKernelGGL(reset_kernel, dim3((an + 255) / 256), dim3(256), 0, e->stream, a);
-    HIPCHK(e, hipGetLastError());
-    hipLaunchKernelGGL(reset_arena_kernel, dim3((e->cfg.n_arenas + 255) / 256), dim3(256), 0, e->stream, a);
-    }
+    HIPCHK(e, launch_reset(e, a));
     HIPCHK(e, hipGetLastError());
     e->orient_valid = true;
     if (flags & CA_F_OBS) HIPCHK(e, launch_obs(e));
@@ -1010,13 +1023,7 @@ int ca_reset_masked(ca_env* e, const int32_t* mask, int32_t mask_is_device, uint
     StepArgs a;
     fill_args(e, a, nullptr, flags);
     a.reset_mask = mask;
-    const unsigned an = (unsigned)AN(e);
-    {
-    ProfScope ps(e, KIND_RESET);
-    hipLaunchKernelGGL(reset_kernel, dim3((an + 255) / 256), dim3(256), 0, e->stream, a);
-    HIPCHK(e, hipGetLastError());
-    hipLaunchKernelGGL(reset_arena_kernel, dim3((A + 255) / 256), dim3(256), 0, e->stream, a);
-    }
+    HIPCHK(e, launch_reset(e, a));
     HIPCHK(e, hipGetLastError());
     if (flags & CA_F_OBS) HIPCHK(e, launch_obs(e));
     return CA_OK;
@@ -1112,7 +1119,7 @@ int ca_alan_step(ca_env* e, const double* u, int32_t u_is_device, uint32_t flags
     const dim3 grid((unsigned)((AN(e) + ALAN_BS - 1) / ALAN_BS)), block(ALAN_BS);
     {
         ProfScope ps(e, KIND_RESET);
-        hipLaunchKernelGGL(alan_select_kernel, grid, block, (size_t)e->n_actions * ALAN_BS * 8, e->stream, p);
+        launch_k(ps, alan_select_kernel, grid, block, (size_t)e->n_actions * ALAN_BS * 8, e->stream, p);
     }
     HIPCHK(e, hipGetLastError());
     StepArgs a;
@@ -1120,7 +1127,7 @@ int ca_alan_step(ca_env* e, const double* u, int32_t u_is_device, uint32_t flags
     HIPCHK(e, launch_step(e, a));
     {
         ProfScope ps(e, KIND_RESET);
-        hipLaunchKernelGGL(alan_update_kernel, grid, block, 0, e->stream, p);
+        launch_k(ps, alan_update_kernel, grid, block, 0, e->stream, p);
     }
     HIPCHK(e, hipGetLastError());
     e->orient_valid = true;
@@ -1149,14 +1156,18 @@ int ca_rollout(ca_env* e, int32_t steps, uint32_t flags) {
     if (!e || steps < 0) return fail(e, CA_EINVAL, "ca_rollout: bad argument");
     HIPCHK(e, hipSetDevice(e->device));
     if (e->quad_roll && !(flags & CA_F_OBS) && steps > 1) {
-        // ONE launch: the workgroup that owns an arena keeps it in registers / LDS for all `steps` steps (ca_quad.h)
-        if (e->prof_period > 1) e->profiling = (e->steps_done % (uint64_t)e->prof_period) == 0;
+        // ONE launch per CA_ROLLOUT_MAX_T steps: the workgroup that owns an arena keeps it in registers / LDS for all of
+        // them (ca_quad.h).  Bounded, so that a long rollout stays a sequence of kernels of a few milliseconds (a kernel
+        // cannot be interrupted, and a watchdog may reset a GPU over one that runs for seconds).
         StepArgs a;
         fill_args(e, a, nullptr, flags);
-        a.T = steps;
-        HIPCHK(e, launch_step(e, a));
+        for (int done = 0; done < steps; done += CA_ROLLOUT_MAX_T) {
+            if (e->prof_period > 1) e->profiling = (e->steps_done / (uint64_t)CA_ROLLOUT_MAX_T) % (uint64_t)e->prof_period == 0;
+            a.T = steps - done < CA_ROLLOUT_MAX_T ? steps - done : CA_ROLLOUT_MAX_T;
+            HIPCHK(e, launch_step(e, a));
+            e->steps_done += (uint64_t)a.T;
+        }
         e->orient_valid = true;
-        e->steps_done += (uint64_t)steps;
         return CA_OK;
     }
     for (int s = 0; s < steps; ++s) {
@@ -1182,7 +1193,6 @@ int ca_get_stats(ca_env* e, ca_stats* out) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     ca_stats s;
     memset(&s, 0, sizeof s);
-    unsigned long long frozen = 0;  // arena-steps skipped under CA_F_FREEZE
     for (size_t a = 0; a < A; ++a) {
         const unsigned long long* r = &h[a * ST_STRIDE];
         s.episodes += r[ST_EPISODES]; s.collisions += r[ST_COLL]; s.obst_collisions += r[ST_OBST_COLL];
@@ -1190,9 +1200,14 @@ int ca_get_stats(ca_env* e, ca_stats* out) {
         double d;
         memcpy(&d, &r[ST_SUMREW], 8);
         s.sum_reward += d;
-        frozen += r[ST_FROZEN];
     }
-    s.agent_steps = (e->steps_done * (uint64_t)e->cfg.n_arenas - frozen) * (uint64_t)e->cfg.n_agents;
+    // agent-steps: counted by the kernels (every solve launch adds, per arena it advanced, the steps it advanced it by)
+    std::vector<unsigned long long> hs(A);
+    HIPCHK(e, hipMemcpyAsync(hs.data(), e->arena_steps, A * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    unsigned long long arena_steps = 0;
+    for (size_t a = 0; a < A; ++a) arena_steps += hs[a];
+    s.agent_steps = arena_steps * (uint64_t)e->cfg.n_agents;
     *out = s;
     return CA_OK;
 }
@@ -1201,6 +1216,7 @@ int ca_reset_stats(ca_env* e) {
     if (!e) return CA_EINVAL;
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipMemsetAsync(e->arena_stats, 0, (size_t)e->cfg.n_arenas * ST_STRIDE * 8, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->arena_steps, 0, (size_t)e->cfg.n_arenas * 8, e->stream));
     e->steps_done = 0;
     return CA_OK;
 }
@@ -1279,7 +1295,8 @@ int ca_profile_read(ca_env* e, int32_t counts[4], float mean_ms[4]) {
     for (int k = 0; k < 4; ++k) counts[k] = 0;
     for (const ca_env::Span& sp : e->spans) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, sp.t0, sp.t1) == hipSuccess) { sum[sp.kind] += ms; counts[sp.kind] += 1; }
+        // (a launch that advanced T steps -- ca_rollout's one-launch form -- is reported per step, like the others)
+        if (hipEventElapsedTime(&ms, sp.t0, sp.t1) == hipSuccess) { sum[sp.kind] += ms / (sp.steps > 0 ? sp.steps : 1); counts[sp.kind] += 1; }
         e->free_events.push_back(sp.t0);
         e->free_events.push_back(sp.t1);
     }
@@ -1299,6 +1316,11 @@ int ca_launch_info(ca_env* e, int32_t* block, int32_t* grid, int32_t* lds_bytes,
     }
     return CA_OK;
 }
+
+#ifndef CA_SRC_SHA
+#define CA_SRC_SHA "unknown"
+#endif
+const char* ca_source_sha(void) { return CA_SRC_SHA; }
 
 int ca_solver_info(ca_env* e, int32_t* lanes_per_agent, int32_t* rollout_one_launch) {
     if (!e) return CA_EINVAL;

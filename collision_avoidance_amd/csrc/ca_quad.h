@@ -167,6 +167,8 @@ template <int KMAX, int BS, int SQ>
 __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
     static_assert(POOL_SLOTS == 16, "a wave holds 16 quads: one line-table slot each");
     static_assert(SQ == 4 || SQ == 16, "obstacle lists of 4 or 16");
+    static_assert(!CA_NBW16(BS / 4), "the quad kernel stores 8-bit agent-neighbour ids: at most 256 agent slots per workgroup "
+                                     "(and not the CA_VAR_NB16 diagnostic build)");
     constexpr int M = KMAX <= 4 ? 4 : (KMAX <= 8 ? 8 : 16);  // merge width of the agent-neighbour lists
     constexpr int ML = SQ + KMAX;
     constexpr int NS = BS / 4;                               // agent slots per workgroup
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
     const float R = p.radius;
     const bool nodone = (p.flags & 8u) != 0;  // CA_F_NODONE
     // per-arena counters of the launch (meaningful in the lanes of agent 0), flushed once at the end
-    unsigned acc_coll = 0, acc_wall = 0, acc_goals = 0, acc_epis = 0, acc_frozen = 0, acc_ovf = 0;
+    unsigned acc_coll = 0, acc_wall = 0, acc_goals = 0, acc_epis = 0, acc_frozen = 0, acc_ovf = 0, acc_steps = 0;
     unsigned long long lastep = 0;
     bool have_lastep = false;
     float ox = pref.x, oy = pref.y;
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
         const bool frozen = (p.flags & 16u) != 0 && in_arena && adone != 0;  // CA_F_FREEZE: the episode of this arena is over
         const bool active = in_arena && !frozen;
         if (frozen && i == 0) acc_frozen += 1;
+        if (active && i == 0) acc_steps += 1;
         touched = touched || active;
         const bool write_lists = (t == T - 1) || (p.flags & 16u) != 0;
 
@@ -560,6 +563,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
             if (have_lastep) st[ST_LASTEP] = lastep;
             c.arena_done[a] = adone;
             c.step_count[a] = steps;
+            c.arena_steps[a] += acc_steps;
         }
     }
 }

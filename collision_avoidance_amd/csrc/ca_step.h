@@ -475,6 +475,7 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
             }
             c.arena_done[a] = all_done ? 1 : 0;
             c.step_count[a] = do_reset ? 0 : steps;
+            c.arena_steps[a] += 1;
             if (do_reset) c.episode[a] = epi + 1;
         }
     }

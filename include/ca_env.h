@@ -127,7 +127,7 @@ typedef struct ca_config {
 } ca_config;
 
 typedef struct ca_stats {
-    uint64_t agent_steps;
+    uint64_t agent_steps;     /* counted IN the solve kernels: per arena, the steps it was really advanced, x n_agents */
     uint64_t episodes;
     uint64_t collisions;      /* overlapping agent pairs after the update, summed over steps  */
     uint64_t obst_collisions; /* agents overlapping an obstacle edge, summed over steps       */
@@ -197,8 +197,9 @@ int ca_orca_step(ca_env* env, uint32_t flags);
 int ca_observe(ca_env* env);
 /* `steps` consecutive ca_orca_step calls without returning to the host (with CA_F_FREEZE: every
  * arena runs to the end of its own episode, at most `steps` steps): the reference's ORCA-only loops, env.py:570-573
- * (`while True: orca_step()`) and ALAN:106-123 (run_sim).  One kernel launch for all the steps where the handle uses
- * the four-lanes-per-agent kernel (ca_solver_info) and no observation is asked for. */
+ * (`while True: orca_step()`) and ALAN:106-123 (run_sim).  One kernel launch per 256 steps where the handle uses
+ * the four-lanes-per-agent kernel (ca_solver_info) and no observation is asked for (a launch is bounded so that a long
+ * rollout stays a sequence of kernels of a few milliseconds; ca_profile_read reports such a launch per step). */
 int ca_rollout(ca_env* env, int32_t steps, uint32_t flags);
 
 /* ALAN online learning (ALAN_true.py:569-628 online_step + the counter / goal test of run_sim,
@@ -242,7 +243,9 @@ int ca_debug_math(ca_env* env, int32_t op, const void* in, void* out, int32_t n)
  * time of the kernel, what rocprofv3 --kernel-trace reports; k = 1: every launch).  ca_profile_read synchronises and
  * returns, per kernel kind, the number of sampled launches and their mean duration in milliseconds since the last read
  * (kinds: 0 nbr_kernel -- only when the neighbour search runs as a launch of its own, CA_FUSE_NBR=0; normally it is the
- * head of step_kernel --, 1 step_kernel, 2 obs_kernel, 3 reset kernels), then clears them.  ca_profile(env, 0) switches
+ * head of step_kernel --, 1 step_kernel -- per STEP: a ca_rollout launch that advances T steps counts as one launch of
+ * duration / T --, 2 obs_kernel, 3 the small kernels: reset_kernel, reset_arena_kernel, the ALAN select / update kernels, each
+ * launch on its own), then clears them.  ca_profile(env, 0) switches
  * it off (default).  A sampled step costs ~10 us of dispatch serialisation; results never depend on it. */
 int ca_profile(ca_env* env, int32_t period);
 int ca_profile_read(ca_env* env, int32_t counts[4], float mean_ms[4]);
@@ -256,6 +259,9 @@ int ca_launch_info(ca_env* env, int32_t* block, int32_t* grid, int32_t* lds_byte
  * *rollout_one_launch = 1: ca_rollout(env, T, flags without CA_F_OBS) is ONE kernel launch that keeps every arena in
  * registers / LDS for its T steps (the four-lanes kernel; chosen up to 1024 waves inclusive); 0: it is T launches. */
 int ca_solver_info(ca_env* env, int32_t* lanes_per_agent, int32_t* rollout_one_launch);
+/* Hash of the kernel sources and compiler flags this library was built from (collision_avoidance_amd/build.py compiles
+ * it in): reports and counter profiles quote it, so that they name the code that ran.  No reference counterpart. */
+const char* ca_source_sha(void);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,34 @@ def test_two_ranks_gloo(tmp_path):
     assert whole[0] == A_TOTAL * N * STEPS
 
 
+def _worker8(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    offset, n_local = cad.weak_shard(2, rank)                    # weak scaling like bench.py: 2 arenas per rank
+    px, gx, st = _run_oracle(offset, n_local)
+    # the job's ONE collective carries the statistics, the device and the rank's own time (bench.py): max over the records
+    per_rank, total = cad.gather_stats(st, extra={"device": rank, "dt_ns": 1000 + 7 * rank})
+    assert max(d["dt_ns"] for d in per_rank) == 1000 + 7 * (world - 1)
+    assert [d["device"] for d in per_rank] == list(range(world))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), px=px, total=np.array([total[k] for k in cad.STAT_KEYS]))
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_gloo(tmp_path):
+    """World size 8 (BASELINE config C4's shape: one shard per GPU, weak scaling) rehearsed on the CPU: the shards
+    are the slices of the single-process run, and every rank ends with the job totals after one all_gather."""
+    port = _free_port()
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    px, gx, st = _run_oracle(0, 16)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(8)]
+    np.testing.assert_array_equal(np.concatenate([p["px"] for p in parts]), px)
+    whole = np.array([st[k] for k in cad.STAT_KEYS])
+    for p in parts:
+        np.testing.assert_array_equal(p["total"], whole)
+    assert whole[0] == 16 * N * STEPS
+
+
 def test_gather_stats_single_process():
     st = dict(agent_steps=10, episodes=1, collisions=2, obst_collisions=0, goals_reached=3,
               obst_overflow=0, sum_reward=1.5)

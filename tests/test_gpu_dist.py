@@ -1,10 +1,12 @@
-"""The N > 1 path of bench.py with the HIP library under it, on the one-GPU box: two gloo ranks share the card
+"""The N > 1 path of bench.py with the HIP library under it, on the one-GPU box: two (and four) gloo ranks share the card
 (CA_BENCH_BACKEND=gloo; the production backend is RCCL, one rank per GPU).  Started as a FRESH child process -- the
 launcher (bench.py::launch_ranks -> torch.distributed.run) must never be reached by re-executing a process that has
 already touched the GPU.  What is checked: the world really has two ranks, each reports its own agent-steps and
 device, and the job statistics that came through the ONE all_gather equal the sum of two single-process runs that
 play rank 0 and rank 1 (arena offsets 0 and 1024: the scenario RNG is keyed by the global arena id; the reference
-replicates environments over workers the same way, run_rllib.py:108)."""
+replicates environments over workers the same way, run_rllib.py:108).  The pool allows at most six processes on the
+card at once, so the widest rehearsal WITH the GPU is world 4 (test process + four ranks); world 8 is rehearsed on the
+CPU (tests/test_dist_cpu.py::test_eight_ranks_gloo)."""
 import json
 import os
 import subprocess
@@ -17,13 +19,13 @@ STEPS, WARM = 50, 10
 INT_KEYS = ("agent_steps", "episodes", "collisions", "obst_collisions", "goals_reached", "obst_overflow")
 
 
-def _bench(extra, env_extra):
+def _bench(extra, env_extra, workload=("--workload", "C2")):
     env = dict(os.environ)
     env.update(env_extra)
     env["CA_BENCH_MIN_WARM"] = "0"      # exactly --warmup steps: the runs below must start the timed region in the same state
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "C2", "--steps", str(STEPS), "--warmup", str(WARM),
-           "--no-cpu-baseline"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + list(workload) + ["--steps", str(STEPS), "--warmup", str(WARM),
+                                                                              "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
@@ -32,17 +34,21 @@ def _bench(extra, env_extra):
 
 
 @pytest.mark.gpu
-def test_two_gloo_ranks_drive_the_hip_library():
-    two = _bench(["--gpus", "2"], {"CA_BENCH_BACKEND": "gloo"})
-    assert two["n_gpus"] == 2 and two["world_size"] == 2 and two["scaling"] == "weak"
-    per_rank = 1024 * 16 * STEPS
-    assert [r["rank"] for r in two["ranks"]] == [0, 1]
-    assert [r["agent_steps"] for r in two["ranks"]] == [per_rank, per_rank]
-    assert two["stats"]["agent_steps"] == 2 * per_rank
-    assert two["value"] > 0 and abs(two["value"] - 2 * 1024 * 16 / (two["ms_per_step"] * 1e-3)) <= 1e-6 * two["value"]
-    singles = [_bench(["--as-rank", str(r)], {}) for r in (0, 1)]
+@pytest.mark.parametrize("world,arenas", [(2, 1024), (4, 128)])
+def test_gloo_ranks_drive_the_hip_library(world, arenas):
+    wl = ("--workload", "C2", "--arenas", str(arenas))
+    job = _bench(["--gpus", str(world)], {"CA_BENCH_BACKEND": "gloo"}, wl)
+    assert job["n_gpus"] == world and job["world_size"] == world and job["scaling"] == "weak"
+    assert job["backend"] == "gloo" and job["collectives"]["data_path"] == 0
+    per_rank = arenas * 16 * STEPS
+    assert [r["rank"] for r in job["ranks"]] == list(range(world))
+    assert [r["agent_steps"] for r in job["ranks"]] == [per_rank] * world      # counted in the kernels, per rank
+    assert job["stats"]["agent_steps"] == world * per_rank
+    assert job["value"] > 0 and abs(job["value"] - world * arenas * 16 / (job["ms_per_step"] * 1e-3)) <= 1e-6 * job["value"]
+    singles = [_bench(["--as-rank", str(r)], {}, wl) for r in range(world)]
     for k in INT_KEYS:
-        assert two["stats"][k] == singles[0]["stats"][k] + singles[1]["stats"][k], (k, two["stats"], [s["stats"] for s in singles])
-    assert two["stats"]["goals_reached"] > 0        # the crowd did something in 50 steps
-    # every rank ran the HIP kernels: the launch geometry is that of the 1024 x 16 shard
-    assert two["launch"] == singles[0]["launch"]
+        assert job["stats"][k] == sum(s["stats"][k] for s in singles), (k, job["stats"], [s["stats"] for s in singles])
+    assert job["stats"]["goals_reached"] > 0        # the crowd did something in 50 steps
+    # every rank ran the HIP kernels: the launch geometry is that of its shard; the line names the code that ran
+    assert job["launch"] == singles[0]["launch"]
+    assert job["src_sha"] == singles[0]["src_sha"] == job["src_sha_on_disk"] != "unknown"

@@ -44,3 +44,48 @@ def test_sampled_kernel_times_are_consistent_and_change_nothing(A, N, K, nd):
         assert np.array_equal(prof.get(f), plain.get(f)), f
     assert prof.profile_read()["step_kernel"][0] == 0   # read clears, and nothing is sampled once switched off
     prof.close(); plain.close()
+
+
+def test_small_kernels_are_timed_on_their_own_dispatch():
+    """Kind 3 of ca_profile_read (reset_kernel, reset_arena_kernel, the ALAN select / update kernels): each launch carries
+    its own start / stop event like the solve and observation kernels -- a sane count and a sane time after ca_reset and
+    ca_alan_step, also with recycled events."""
+    A, N = 64, 16
+    p = H.scenario_params("crowd", N)
+    env = H.make_gpu(A, N, "crowd", p, seed=2)
+    env.alan_configure([[1.0, 0.0], [0.7, 0.7], [0.7, -0.7], [0.0, 1.0]])
+    for rnd in range(2):                      # the second round reuses the events the first one handed back
+        env.profile(1)
+        env.profile_read()
+        env.reset(with_obs=False)             # reset_kernel + reset_arena_kernel: 2 launches
+        for s in range(5):
+            env.alan_step(stats=True)         # select + solve + update: 2 small launches and 1 solve launch each
+        t = env.profile_read()
+        env.profile(0)
+        assert t["reset_kernels"][0] == 2 + 2 * 5, t
+        assert t["step_kernel"][0] == 5 and t["obs_kernel"][0] == 0, t
+        assert 1e-4 < t["reset_kernels"][1] < 1.0, t          # milliseconds: a few microseconds each, never negative / stale
+        assert 1e-3 < t["step_kernel"][1] < 5.0, t
+    env.close()
+
+
+def test_one_launch_rollout_is_reported_per_step():
+    """ca_rollout's one-launch form advances T steps per launch (at most 256): ca_profile_read reports such a launch per
+    step, so a consumer never sees a `step_kernel` time that is T times a step's."""
+    A, N = 64, 16
+    p = scenarios.bench_params(N, 1.5, 5)
+    env = H.make_gpu(A, N, "crowd", p, seed=2)
+    assert env.launch_info()["rollout_one_launch"] == 1
+    env.rollout(50, stats=True)
+    env.profile(1)
+    env.profile_read()
+    for s in range(20):
+        env.orca_step(stats=True)
+    single = env.profile_read()["step_kernel"]
+    env.rollout(600, stats=True)              # 256 + 256 + 88 steps: three launches
+    multi = env.profile_read()["step_kernel"]
+    env.profile(0)
+    assert single[0] == 20 and multi[0] == 3, (single, multi)
+    assert multi[1] < 1.5 * single[1], (single, multi)      # per step (one launch per step pays the launch on top)
+    assert env.stats()["agent_steps"] == A * N * (50 + 20 + 600)
+    env.close()
