@@ -5,7 +5,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcaenv.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("ca_env.hip", "ca_kernels.h", "ca_common.h", "ca_lp.h", "ca_lines.h", "ca_nbr.h", "ca_step.h", "ca_quad.h",
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("ca_env.hip", "ca_kernels.h", "ca_common.h", "ca_lp.h", "ca_lines.h", "ca_nbr.h", "ca_step.h", "ca_quad.h", "ca_pair.h",
                                                     "ca_alan.h", "ca_obs.h", "ca_math.h")] + \
           [os.path.join(os.path.dirname(_HERE), "include", "ca_env.h")]
 # -ffp-contract=off: no FMA contraction -- the numerics contract shared with the parity oracle.

@@ -64,6 +64,8 @@ struct ca_env {
     bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
     int ST = 0, KT = 16;  // solve-kernel variant: ST > 0 = register lines with ST obstacle slots; KT = KMAX
     bool help = false;     // large arenas: helper lanes in the uniform-grid neighbour scan (ca_nbr.h, HELP = 2)
+    bool pair = false;     // large arenas: two lanes per agent for the whole step (ca_pair.h); replaces `help` where chosen
+    size_t lds_p = 0;
     bool quad = false;     // four lanes per agent (ca_quad.h): small batches / small arenas
     bool quad_roll = false;  // ... for ca_rollout's one-launch-for-T-steps form (pays a little longer than for single steps)
     int BSq = 64, grid_q = 1, SQ = 4;   // SQ: obstacle-neighbour capacity of the quad variant (4 or 16)
@@ -242,6 +244,11 @@ static hipError_t launch_step_kf(ca_env* e, const StepArgs& a) {
     const dim3 grid(e->grid), block(e->BS);
     ProfScope ps(e, KIND_STEP);
     if constexpr (FUSE && ST > 0) {
+        if (e->pair) {  // two lanes per agent (ca_pair.h): one arena per workgroup of 2 P lanes
+            if (e->BS == 256) launch_k(ps, pair_kernel<KMAX, 256>, grid, dim3(512), e->lds_p, e->stream, a);
+            else launch_k(ps, pair_kernel<KMAX, 512>, grid, dim3(1024), e->lds_p, e->stream, a);
+            return hipGetLastError();
+        }
         if (e->help) {  // twice the lanes: the upper half helps in the neighbour scan of its arena and ends (ca_nbr.h)
             if (e->BS == 256) launch_k(ps, step_kernel<KMAX, 256, ST, true, 2>, grid, dim3(512), e->lds, e->stream, a);
             else launch_k(ps, step_kernel<KMAX, 512, ST, true, 2>, grid, dim3(1024), e->lds, e->stream, a);
@@ -520,6 +527,12 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->help = !(v && v[0] == '0') && e->fuse_nbr && e->ST > 0 && (e->BS == 256 || e->BS == 512) &&
                   cfg->n_agents >= 192 && e->K > 0;
     }
+    {   // two lanes per agent for the whole step (ca_pair.h) where the helper lanes were: a 512-agent arena is 8 waves of one
+        // lane per agent on its CU -- two per SIMD, each a long dependent chain; 16 waves with half the chain each fill it
+        const char* v = getenv("CA_PAIR");  // diagnostic switch: 0 = the lane kernel with helper lanes in the scan
+        e->pair = e->help && !(v && v[0] == '0');
+        e->lds_p = pair_lds_bytes(e->BS, e->KT);
+    }
     {   // four lanes per agent (ca_quad.h) where one lane per agent would leave SIMDs without a wave: fewer than 1024
         // waves.  Measured crossover (profiles/r03_d_lane_vs_quad_by_batch_size.txt): 16-agent arenas -- quad ahead up to
         // 2048 arenas (512 lane-waves), behind from 4096 (1024); 64-agent arenas -- ahead up to 512 arenas, level at 1024.
@@ -568,9 +581,16 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     if (r == hipSuccess) r = dalloc(e, &e->obs, an * CA_OBS_DIM);
     if (r == hipSuccess) r = dalloc(e, &e->d_obst, (size_t)1);
 #ifdef CA_STAMPS
-    if (r == hipSuccess) r = dalloc(e, &e->dbg, (size_t)std::max(std::max(e->grid * (e->BS / 64), e->grid_n * (e->BSn / 64)), e->grid_q * (e->BSq / 64)) * 16);
+    if (r == hipSuccess) r = dalloc(e, &e->dbg, (size_t)std::max(std::max(e->grid * (2 * e->BS / 64), e->grid_n * (e->BSn / 64)), e->grid_q * (e->BSq / 64)) * 16);
     if (r == hipSuccess) r = dalloc(e, &e->dbg_obs, (size_t)cfg->n_arenas * ((cfg->n_agents + 15) / 16 + 16) * 4 * 16);
 #endif
+    if (r == hipSuccess && e->pair) {
+        const void* f = e->KT == 5 ? (e->BS == 256 ? reinterpret_cast<const void*>(&pair_kernel<5, 256>)
+                                                   : reinterpret_cast<const void*>(&pair_kernel<5, 512>))
+                                   : (e->BS == 256 ? reinterpret_cast<const void*>(&pair_kernel<10, 256>)
+                                                   : reinterpret_cast<const void*>(&pair_kernel<10, 512>));
+        r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_p);
+    }
     if (r == hipSuccess && e->help && e->lds > 48 * 1024) {
         const void* f = e->KT == 5 ? (e->BS == 256 ? reinterpret_cast<const void*>(&step_kernel<5, 256, 4, true, 2>)
                                                    : reinterpret_cast<const void*>(&step_kernel<5, 512, 4, true, 2>))
@@ -1263,7 +1283,7 @@ int ca_debug_stamps(ca_env* e, unsigned long long* out, int32_t max_waves, int32
     if (!e || !e->dbg) return fail(e, CA_EINVAL, "ca_debug_stamps: not a CA_STAMPS build");
     const bool obs = max_waves < 0;  // negative: the observation kernel's stamps
     if (obs) max_waves = -max_waves;
-    const int nw = obs ? e->cfg.n_arenas * ((e->cfg.n_agents + 15) / 16) * 4 : (e->quad ? e->grid_q * (e->BSq / 64) : e->grid * (e->BS / 64));
+    const int nw = obs ? e->cfg.n_arenas * ((e->cfg.n_agents + 15) / 16) * 4 : (e->quad ? e->grid_q * (e->BSq / 64) : e->grid * ((e->pair ? 2 : 1) * e->BS / 64));
     if (n_waves) *n_waves = nw;
     const int n = nw < max_waves ? nw : max_waves;
     HIPCHK(e, hipSetDevice(e->device));
@@ -1307,9 +1327,9 @@ int ca_profile_read(ca_env* e, int32_t counts[4], float mean_ms[4]) {
 
 int ca_launch_info(ca_env* e, int32_t* block, int32_t* grid, int32_t* lds_bytes, int32_t* obs_grid) {
     if (!e) return CA_EINVAL;
-    if (block) *block = e->quad ? e->BSq : e->BS;
+    if (block) *block = e->quad ? e->BSq : (e->pair ? 2 * e->BS : e->BS);
     if (grid) *grid = e->quad ? e->grid_q : e->grid;
-    if (lds_bytes) *lds_bytes = (int32_t)(e->quad ? e->lds_q : e->lds);
+    if (lds_bytes) *lds_bytes = (int32_t)(e->quad ? e->lds_q : (e->pair ? e->lds_p : e->lds));
     if (obs_grid) {
         const int apb = obs_block_threads(e->cfg.n_agents) / 16;
         *obs_grid = (int32_t)((size_t)e->cfg.n_arenas * ((e->cfg.n_agents + apb - 1) / apb));
@@ -1324,7 +1344,7 @@ const char* ca_source_sha(void) { return CA_SRC_SHA; }
 
 int ca_solver_info(ca_env* e, int32_t* lanes_per_agent, int32_t* rollout_one_launch) {
     if (!e) return CA_EINVAL;
-    if (lanes_per_agent) *lanes_per_agent = e->quad ? 4 : 1;
+    if (lanes_per_agent) *lanes_per_agent = e->quad ? 4 : (e->pair ? 2 : 1);
     if (rollout_one_launch) *rollout_one_launch = e->quad_roll ? 1 : 0;
     return CA_OK;
 }

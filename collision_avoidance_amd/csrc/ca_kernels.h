@@ -10,6 +10,9 @@
 //   * quad kernel (ca_quad.h): FOUR lanes per agent for small arenas (a chip of 1024 SIMDs is otherwise left with a
 //     few hundred waves): candidates, edges, lines and LP1 clips are dealt over the quad and merged with DPP moves;
 //     one launch can advance T ORCA-only steps with the arena resident in registers / LDS (ca_rollout).
+//   * pair kernel (ca_pair.h): TWO lanes per agent for large arenas (192 .. 512 agents: one arena per workgroup is otherwise
+//     two waves per SIMD, each a long dependent chain): grid-scan candidates, half-planes and LP1 clips dealt over the pair,
+//     lines in registers (slot m of the even / odd lane = neighbour 2 m / 2 m + 1), merges by DPP.
 //   * obs_kernel (ca_obs.h): 16 lanes per agent, one lane per (source, ray) pair, ds_min_u64 merge per ray.
 // Arenas are independent, so there is no inter-workgroup traffic; the grids are arena-major, and the observation workgroups of
 // an arena are indexed so that they run on the XCD whose solve workgroup wrote the arena's state (ca_obs.h).
@@ -27,6 +30,7 @@
 #pragma once
 #include "ca_step.h"
 #include "ca_quad.h"
+#include "ca_pair.h"
 #include "ca_alan.h"
 #include "ca_obs.h"
 

@@ -1,0 +1,86 @@
+"""Large arenas (192 .. 512 agents): the two-lanes-per-agent solve kernel (csrc/ca_pair.h) is the default there and the
+lane kernel with helper lanes in the scan (CA_PAIR=0) its fallback -- both against the oracle, bit for bit, and against
+each other.  The pair kernel works through the arena in the order of its uniform grid, so per-agent results must not
+depend on where in that order an agent sits: actions, rewards, observation, auto-reset and per-arena freezing included."""
+import os
+
+import numpy as np
+import pytest
+
+from collision_avoidance_amd import _lib
+from oracle import oracle as o
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _with_pair(value, fn):
+    old = os.environ.get("CA_PAIR")
+    os.environ["CA_PAIR"] = value
+    try:
+        return fn()
+    finally:
+        if old is None:
+            del os.environ["CA_PAIR"]
+        else:
+            os.environ["CA_PAIR"] = old
+
+
+def test_pair_kernel_is_the_default_for_large_arenas_only():
+    for N, lanes in ((512, 2), (300, 2), (192, 2), (191, 1), (64, 1), (1000, 1)):
+        g = H.make_gpu(2 if N < 1000 else 1, N, "crowd", H.scenario_params("crowd", N), seed=1)
+        assert g.launch_info()["lanes_per_agent"] == lanes, (N, g.launch_info())
+        g.close()
+    g = _with_pair("0", lambda: H.make_gpu(2, 300, "crowd", H.scenario_params("crowd", 300), seed=1))
+    assert g.launch_info()["lanes_per_agent"] == 1
+    g.close()
+    # K = 16 or more than four obstacle neighbours need the LDS line table: one lane per agent
+    g = H.make_gpu(2, 250, "crowd", H.scenario_params("crowd", 250, max_neighbors=16), seed=1)
+    assert g.launch_info()["lanes_per_agent"] == 1
+    g.close()
+
+
+@pytest.mark.parametrize("N,K,nd,scenario", [(512, 10, 5.0, "crowd"), (300, 7, 4.0, "crowd"), (200, 3, 2.0, "crowd"),
+                                             (256, 10, 5.0, "circle"), (226, 10, 5.0, "incoming")])
+def test_pair_and_helper_variants_step_with_actions_obs_autoreset(N, K, nd, scenario):
+    """Full steps (actions in, reward and observation out) with statistics and auto-reset, a short episode cap so that the
+    reset happens inside the run: the default (pair) kernel, the CA_PAIR=0 fallback and the oracle agree bit for bit."""
+    A = 3
+    p = H.scenario_params(scenario, N, max_neighbors=K, neighbor_dist=nd, max_step=7)
+    pair = H.make_gpu(A, N, scenario, p, seed=9)
+    help_ = _with_pair("0", lambda: H.make_gpu(A, N, scenario, p, seed=9))
+    orc = H.make_oracle(A, N, scenario, p, seed=9)
+    assert pair.launch_info()["lanes_per_agent"] == 2 and help_.launch_info()["lanes_per_agent"] == 1
+    rng = np.random.RandomState(3)
+    for s in range(16):
+        act = rng.uniform(-1.0, 1.0, (A, N)).astype(np.float32)
+        pair.step(act, stats=True, autoreset=True)
+        help_.step(act, stats=True, autoreset=True)
+        orc.step(act, flags=o.F_OBS | o.F_STATS | o.F_AUTORESET)
+        if s % 5 == 4 or s == 15:
+            H.assert_state_equal(pair, orc, "pair step %d" % s, obs=True, reward=True)
+            H.assert_state_equal(help_, orc, "helper step %d" % s, obs=True, reward=True)
+    H.assert_stats_equal(pair, orc, "pair")
+    H.assert_stats_equal(help_, orc, "helper")
+    assert pair.stats()["episodes"] >= 2 * A      # the cap of 7 steps ended (and restarted) every arena at least twice
+    np.testing.assert_array_equal(pair.get(_lib.FLD_ARENA_STATS)[:, [0, 1, 2, 3, 4, 6, 7]],
+                                  orc.get(o.FLD_ARENA_STATS)[:, [0, 1, 2, 3, 4, 6, 7]])
+    pair.close(); help_.close()
+
+
+def test_pair_done_modes_and_freeze():
+    """The goal test of ALAN:547-566 (arrival -> second goal, arrival step recorded) and per-arena freezing under the pair
+    kernel: a 200-agent circle whose agents arrive at different times, rolled out with CA_F_FREEZE."""
+    A, N = 2, 200
+    p = H.scenario_params("circle", N, max_step=40)
+    g = H.make_gpu(A, N, "circle", p, seed=4)
+    e = H.make_oracle(A, N, "circle", p, seed=4)
+    assert g.launch_info()["lanes_per_agent"] == 2
+    g.set(_lib.FLD_STEP_COUNT, np.array([0, 25], np.int32)); e.set(o.FLD_STEP_COUNT, np.array([0, 25], np.int32))
+    for s in range(30):       # arena 1 hits the cap after 15 steps and is frozen from then on
+        g.orca_step(stats=True, freeze=True); e.orca_step(flags=o.F_STATS | o.F_FREEZE)
+    H.assert_state_equal(g, e, "freeze")
+    H.assert_stats_equal(g, e, "freeze")
+    assert g.get(_lib.FLD_ARENA_DONE).tolist() == [0, 1] and g.stats()["agent_steps"] == N * (30 + 15)
+    np.testing.assert_array_equal(g.get(_lib.FLD_ARRIVE_STEP), e.get(o.FLD_ARRIVE_STEP))
+    g.close()

@@ -34,7 +34,12 @@ names = ["load+pref+stage", "list counts", "(unused)", "obst lines", "agent line
 if env.launch_info()["lanes_per_agent"] == 4:   # the quad kernel stamps its own phases (csrc/ca_quad.h)
     names = ["pref+stage arena", "obstacle nbrs+merge", "agent scan+merge+lists", "obst lines", "agent lines", "LP2",
              "LP3+integrate", "barriers+stats", "reward/pref", "done test+reduce", "reset/orient/tail"]
+if env.launch_info()["lanes_per_agent"] == 2:   # the pair kernel stamps its own phases (csrc/ca_pair.h)
+    names = ["load+pref+stage", "grid build+remap", "obstacle nbrs", "grid scan+merge", "lists+obst lines", "agent lines", "LP2",
+             "LP3+integrate", "wait at the barrier", "2 barriers+stats", "reward+done+tail"]
 acc, nacc = [], []
+WARM = int(os.environ.get("CA_STAMPS_WARM", "3000"))   # the crowd settles over the first seconds: stamp the settled one
+env.rollout(WARM, stats=True)
 for s in range(120):
     if mode == "step":
         env.step(rng.uniform(-0.5, 0.5, (A, N)).astype(np.float32), with_obs=False, stats=True)
@@ -42,7 +47,7 @@ for s in range(120):
         env.orca_step(stats=True)
     if s >= 100:
         nw = C.c_int32()
-        buf = np.zeros((A * max(1, N // 16) * 2, 16), np.uint64)
+        buf = np.zeros((A * max(1, N // 16) * 4, 16), np.uint64)
         env._call("ca_debug_stamps", env.h, buf.ctypes.data, buf.shape[0], C.byref(nw))
         t = buf[:nw.value, :12].astype(np.int64)
         acc.append(np.diff(t, axis=1))
@@ -89,7 +94,7 @@ print("%s %s: %d waves sampled, mean cycles/wave %.0f (p50 %.0f, p95 %.0f)" %
 for k, n in enumerate(names):
     print("  %-18s %8.0f cycles  %5.1f %%   (p95 %6.0f)" % (n, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean(),
                                                            np.percentile(d[:, k], 95)))
-if env.launch_info()["lanes_per_agent"] == 4:
+if env.launch_info()["lanes_per_agent"] != 1:
     raise SystemExit(0)
 nd = np.concatenate(nacc)
 print("nbr_kernel: %d waves sampled, mean cycles/wave (first to last stamp) %.0f" % (len(nd), nd.sum(axis=1).mean()))
