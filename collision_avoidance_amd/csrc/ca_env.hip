@@ -63,6 +63,8 @@ struct ca_env {
     int BSn = 64, grid_n = 1;  // the neighbour kernel's own workgroup size
     bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
     int ST = 0, KT = 16;  // solve-kernel variant: ST > 0 = register lines with ST obstacle slots; KT = KMAX
+    int SMX = 4;          // ... and the capacity of its obstacle-neighbour list (4, or 16: agents with more than ST are solved apart)
+    int max_edges = 0;    // edges of the largest installed obstacle table (the variant depends on it: pick_variant)
     bool help = false;     // large arenas: helper lanes in the uniform-grid neighbour scan (ca_nbr.h, HELP = 2)
     bool pair = false;     // large arenas: two lanes per agent for the whole step (ca_pair.h); replaces `help` where chosen
     size_t lds_p = 0;
@@ -255,6 +257,18 @@ static hipError_t launch_step_kf(ca_env* e, const StepArgs& a) {
             return hipGetLastError();
         }
     }
+    if constexpr (FUSE && ST > 0) {
+        if (e->SMX > ST) {  // register lines, obstacle-neighbour lists of up to 16 (agents with more than ST are solved apart)
+            switch (e->BS) {
+                case 64: launch_k(ps, step_kernel<KMAX, 64, ST, true, 1, 16>, grid, block, e->lds, e->stream, a); break;
+                case 128: launch_k(ps, step_kernel<KMAX, 128, ST, true, 1, 16>, grid, block, e->lds, e->stream, a); break;
+                case 256: launch_k(ps, step_kernel<KMAX, 256, ST, true, 1, 16>, grid, block, e->lds, e->stream, a); break;
+                case 512: launch_k(ps, step_kernel<KMAX, 512, ST, true, 1, 16>, grid, block, e->lds, e->stream, a); break;
+                default: launch_k(ps, step_kernel<KMAX, 1024, ST, true, 1, 16>, grid, block, e->lds, e->stream, a); break;
+            }
+            return hipGetLastError();
+        }
+    }
     switch (e->BS) {  // (neighbour search +) lines + LP + integration + reward/done
         case 64: launch_k(ps, step_kernel<KMAX, 64, ST, FUSE>, grid, block, e->lds, e->stream, a); break;
         case 128: launch_k(ps, step_kernel<KMAX, 128, ST, FUSE>, grid, block, e->lds, e->stream, a); break;
@@ -302,6 +316,11 @@ static hipError_t set_lds_attr(size_t lds) {
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KMAX, BS, ST, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (r != hipSuccess) return r;
+    if constexpr (ST > 0) {
+        r = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KMAX, BS, ST, true, 1, 16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (r != hipSuccess) return r;
+    }
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KMAX, BS, ST, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
@@ -465,6 +484,78 @@ static hipError_t download(ca_env* e, void* dst, const void* src, size_t bytes) 
     return r != hipSuccess ? r : hipStreamSynchronize(e->stream);
 }
 
+// + the statically allocated LDS of the fused neighbour search: positions, and for >= 256 lanes the grid tables
+static size_t lds_static_bytes(const ca_env* e) {
+    return (e->help ? (size_t)e->KT * e->BS * 8 : 0) + (size_t)e->BS * 8 +
+           (e->BS >= 1024 ? (size_t)e->BS * 2 + 16 + 1024 + 1028 : (e->BS >= 256 ? (size_t)e->BS * 2 + (size_t)e->BS * 8 + 16 + 4096 + 4100 : 0)) + 64;
+}
+
+// Which solve kernel (lane-per-agent family) serves this handle.  Register-resident ORCA lines (ST = 4 obstacle slots + KMAX
+// neighbour slots, LP2 / LP1 unrolled, no scratch) when K <= 10 and
+//   * the obstacle-neighbour list holds at most 4 entries (the synthetic crowds: one boundary polygon), or
+//   * it holds up to 16 and the world is SMALL (at most 16 edges per arena: the reference env's own doorway world, 14 edges
+//     after processObstacles, env.py:117-122; "congested", ALAN:195-208) -- there an agent practically never has more than
+//     four edges in range (none in 3.8e5 sampled agent-steps of either world), and the one that does is solved apart, exactly
+//     (ca_step.h solve_many_obstacles), so the list capacity stays RVO2's "every edge in range" --, or
+//   * the LDS line table would not fit (arenas above 256 agents with many obstacle neighbours).
+// Else the LDS line table (ST = 0): worlds like the two-way tube ("deadlock": 42 edges, 17 % of the agent-steps with more
+// than four in range).  Called by ca_create (no table yet) and again whenever tables are installed: every variant computes
+// the same bits, so a handle may change variant between steps.
+static void pick_variant(ca_env* e) {
+    const char* v = getenv("CA_REG_LINES");  // diagnostic switch: 0 forces the LDS line table, 1 the register lines wherever they exist
+    const bool allow = !(v && v[0] == '0'), force = v && v[0] == '1';
+    e->KT = e->K <= 5 ? 5 : (e->K <= 10 ? 10 : 16);
+    bool table_fits;
+    {
+        const bool h0 = e->help;
+        e->help = false;   // (the LDS line table never runs with helper lanes)
+        table_fits = step_lds_bytes(e->BS, e->K, e->S, 0, e->KT) + lds_static_bytes(e) <= 160 * 1024;
+        e->help = h0;
+    }
+    const bool small_world = e->max_edges <= 16;
+    if (allow && e->K <= 10 && e->S <= 4) { e->ST = 4; e->SMX = 4; }
+    else if (allow && e->K <= 10 && e->fuse_nbr && (small_world || force || !table_fits)) { e->ST = 4; e->SMX = 16; }
+    else { e->ST = 0; e->SMX = 16; }
+    e->lds = step_lds_bytes(e->BS, e->K, e->S, e->ST, e->KT);
+    {   // helper lanes for the uniform-grid neighbour scan: arenas of 192 .. 512 agents on the register-line kernel
+        const char* h = getenv("CA_NBR_HELP");  // diagnostic switch: 0 = none
+        e->help = !(h && h[0] == '0') && e->fuse_nbr && e->ST > 0 && e->SMX == 4 && (e->BS == 256 || e->BS == 512) &&
+                  e->cfg.n_agents >= 192 && e->K > 0;
+    }
+    {   // two lanes per agent for the whole step (ca_pair.h) where the helper lanes were: a 512-agent arena is 8 waves of one
+        // lane per agent on its CU -- two per SIMD, each a long dependent chain; 16 waves with half the chain each fill it
+        const char* pv = getenv("CA_PAIR");  // diagnostic switch: 0 = the lane kernel with helper lanes in the scan
+        e->pair = e->help && !(pv && pv[0] == '0');
+        e->lds_p = pair_lds_bytes(e->BS, e->KT);
+    }
+}
+
+// the dynamic-LDS limits of the kernels pick_variant chose
+static hipError_t apply_variant_attributes(ca_env* e) {
+    hipError_t r = hipSuccess;
+    if (r == hipSuccess && e->pair) {
+        const void* f = e->KT == 5 ? (e->BS == 256 ? reinterpret_cast<const void*>(&pair_kernel<5, 256>)
+                                                   : reinterpret_cast<const void*>(&pair_kernel<5, 512>))
+                                   : (e->BS == 256 ? reinterpret_cast<const void*>(&pair_kernel<10, 256>)
+                                                   : reinterpret_cast<const void*>(&pair_kernel<10, 512>));
+        r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_p);
+    }
+    if (r == hipSuccess && e->help && e->lds > 48 * 1024) {
+        const void* f = e->KT == 5 ? (e->BS == 256 ? reinterpret_cast<const void*>(&step_kernel<5, 256, 4, true, 2>)
+                                                   : reinterpret_cast<const void*>(&step_kernel<5, 512, 4, true, 2>))
+                                   : (e->BS == 256 ? reinterpret_cast<const void*>(&step_kernel<10, 256, 4, true, 2>)
+                                                   : reinterpret_cast<const void*>(&step_kernel<10, 512, 4, true, 2>));
+        r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds);
+    }
+    if (r == hipSuccess && e->lds > 48 * 1024) {
+        if (e->ST > 0) r = e->KT == 5 ? set_lds_attr_k<5, 4>(e->BS, e->lds) : set_lds_attr_k<10, 4>(e->BS, e->lds);
+        else if (e->K <= 5) r = set_lds_attr_k<5, 0>(e->BS, e->lds);
+        else if (e->K <= 10) r = set_lds_attr_k<10, 0>(e->BS, e->lds);
+        else r = set_lds_attr_k<16, 0>(e->BS, e->lds);
+    }
+    return r;
+}
+
 extern "C" {
 
 const char* ca_last_error(const ca_env* env) { return env ? env->err.c_str() : g_create_err.c_str(); }
@@ -515,24 +606,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     }
     e->K = cfg->max_neighbors;
     e->S = cfg->max_obst_neighbors;
-    {   // solve-kernel variant: register-resident ORCA lines when the configuration fits its slots
-        const char* v = getenv("CA_REG_LINES");  // diagnostic switch: 0 forces the LDS line table
-        const bool allow = !(v && v[0] == '0');
-        e->KT = e->K <= 5 ? 5 : (e->K <= 10 ? 10 : 16);
-        e->ST = (allow && e->K <= 10 && e->S <= 4) ? 4 : 0;
-    }
-    e->lds = step_lds_bytes(e->BS, e->K, e->S, e->ST, e->KT);
-    {   // helper lanes for the uniform-grid neighbour scan: arenas of 192 .. 512 agents on the register-line kernel
-        const char* v = getenv("CA_NBR_HELP");  // diagnostic switch: 0 = none
-        e->help = !(v && v[0] == '0') && e->fuse_nbr && e->ST > 0 && (e->BS == 256 || e->BS == 512) &&
-                  cfg->n_agents >= 192 && e->K > 0;
-    }
-    {   // two lanes per agent for the whole step (ca_pair.h) where the helper lanes were: a 512-agent arena is 8 waves of one
-        // lane per agent on its CU -- two per SIMD, each a long dependent chain; 16 waves with half the chain each fill it
-        const char* v = getenv("CA_PAIR");  // diagnostic switch: 0 = the lane kernel with helper lanes in the scan
-        e->pair = e->help && !(v && v[0] == '0');
-        e->lds_p = pair_lds_bytes(e->BS, e->KT);
-    }
+    pick_variant(e);
     {   // four lanes per agent (ca_quad.h) where one lane per agent would leave SIMDs without a wave: fewer than 1024
         // waves.  Measured crossover (profiles/r03_d_lane_vs_quad_by_batch_size.txt): 16-agent arenas -- quad ahead up to
         // 2048 arenas (512 lane-waves), behind from 4096 (1024); 64-agent arenas -- ahead up to 512 arenas, level at 1024.
@@ -549,12 +623,10 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->grid_q = (cfg->n_arenas + apbq - 1) / apbq;
         e->lds_q = quad_lds_bytes(e->BSq, e->KT, e->SQ);
     }
-    // + the statically allocated LDS of the fused neighbour search: positions, and for >= 256 lanes the grid tables
-    const size_t lds_static = (e->help ? (size_t)e->KT * e->BS * 8 : 0) + (size_t)e->BS * 8 + (e->BS >= 1024 ? (size_t)e->BS * 2 + 16 + 1024 + 1028 : (e->BS >= 256 ? (size_t)e->BS * 2 + (size_t)e->BS * 8 + 16 + 4096 + 4100 : 0)) + 64;
-    if (e->lds + lds_static > 160 * 1024) {
+    if (e->lds + lds_static_bytes(e) > 160 * 1024) {
         fail(nullptr, CA_ERANGE, "ca_create: the solve kernel would need %zu B of LDS (> 160 KiB) for n_agents=%d, "
-             "max_neighbors=%d, max_obst_neighbors=%d: arenas above 256 agents need max_neighbors <= 10 and "
-             "max_obst_neighbors <= 4 (register-line variant)", e->lds + lds_static, cfg->n_agents, e->K, e->S);
+             "max_neighbors=%d, max_obst_neighbors=%d: arenas above 256 agents need max_neighbors <= 10 "
+             "(register-line variant)", e->lds + lds_static_bytes(e), cfg->n_agents, e->K, e->S);
         if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
         delete e;
         return CA_ERANGE;
@@ -584,26 +656,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     if (r == hipSuccess) r = dalloc(e, &e->dbg, (size_t)std::max(std::max(e->grid * (2 * e->BS / 64), e->grid_n * (e->BSn / 64)), e->grid_q * (e->BSq / 64)) * 16);
     if (r == hipSuccess) r = dalloc(e, &e->dbg_obs, (size_t)cfg->n_arenas * ((cfg->n_agents + 15) / 16 + 16) * 4 * 16);
 #endif
-    if (r == hipSuccess && e->pair) {
-        const void* f = e->KT == 5 ? (e->BS == 256 ? reinterpret_cast<const void*>(&pair_kernel<5, 256>)
-                                                   : reinterpret_cast<const void*>(&pair_kernel<5, 512>))
-                                   : (e->BS == 256 ? reinterpret_cast<const void*>(&pair_kernel<10, 256>)
-                                                   : reinterpret_cast<const void*>(&pair_kernel<10, 512>));
-        r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_p);
-    }
-    if (r == hipSuccess && e->help && e->lds > 48 * 1024) {
-        const void* f = e->KT == 5 ? (e->BS == 256 ? reinterpret_cast<const void*>(&step_kernel<5, 256, 4, true, 2>)
-                                                   : reinterpret_cast<const void*>(&step_kernel<5, 512, 4, true, 2>))
-                                   : (e->BS == 256 ? reinterpret_cast<const void*>(&step_kernel<10, 256, 4, true, 2>)
-                                                   : reinterpret_cast<const void*>(&step_kernel<10, 512, 4, true, 2>));
-        r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds);
-    }
-    if (r == hipSuccess && e->lds > 48 * 1024) {
-        if (e->ST > 0) r = e->KT == 5 ? set_lds_attr_k<5, 4>(e->BS, e->lds) : set_lds_attr_k<10, 4>(e->BS, e->lds);
-        else if (e->K <= 5) r = set_lds_attr_k<5, 0>(e->BS, e->lds);
-        else if (e->K <= 10) r = set_lds_attr_k<10, 0>(e->BS, e->lds);
-        else r = set_lds_attr_k<16, 0>(e->BS, e->lds);
-    }
+    if (r == hipSuccess) r = apply_variant_attributes(e);
     if (r == hipSuccess && e->quad_roll && e->lds_q > 48 * 1024)
         r = hipFuncSetAttribute(quad_fn(e), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_q);
     if (r == hipSuccess) {
@@ -729,6 +782,13 @@ static int install_tables(ca_env* e, std::vector<ObstDev>& all, std::vector<int>
     e->d_tab_off = n_off;
     e->h_obst.swap(all);
     e->h_tab_off.swap(offs);
+    // the solve-kernel variant depends on the size of the world (pick_variant)
+    int me = 0;
+    if (e->h_tab_off.empty()) me = (int)e->h_obst.size();
+    else for (size_t a = 0; a + 1 < e->h_tab_off.size(); ++a) me = std::max(me, e->h_tab_off[a + 1] - e->h_tab_off[a]);
+    e->max_edges = me;
+    pick_variant(e);
+    HIPCHK(e, apply_variant_attributes(e));
     return CA_OK;
 }
 

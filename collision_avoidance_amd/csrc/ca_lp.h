@@ -227,11 +227,12 @@ __device__ __forceinline__ int quad_xor(int v) { return __builtin_amdgcn_update_
 template <int CTRL>
 __device__ __forceinline__ float quad_xor(float v) { return __int_as_float(quad_xor<CTRL>(__float_as_int(v))); }
 
-__device__ __noinline__ void lp3_coop(float4* pool, int ML, int nslots, float radius) {
+// (stride: slots per row of the pool -- POOL_SLOTS; 1 for the single-agent table of ca_step.h solve_many_obstacles)
+__device__ __noinline__ void lp3_coop(float4* pool, int ML, int nslots, float radius, int stride = POOL_SLOTS) {
     const int lane = threadIdx.x & 63, slot = lane >> 2, q = lane & 3;
-    float4* hdr = pool + (size_t)(2 * ML - 1) * POOL_SLOTS;
-    LdsLines ls; ls.base = pool + slot; ls.stride = POOL_SLOTS;
-    LdsLines pj; pj.base = pool + (size_t)ML * POOL_SLOTS + slot; pj.stride = POOL_SLOTS;
+    float4* hdr = pool + (size_t)(2 * ML - 1) * stride;
+    LdsLines ls; ls.base = pool + slot; ls.stride = stride;
+    LdsLines pj; pj.base = pool + (size_t)ML * stride + slot; pj.stride = stride;
     const bool live = slot < nslots;
     const float4 h = live ? hdr[slot] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const int packed = __float_as_int(h.z);

@@ -119,6 +119,13 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
         }
     }
     const int ocnt = oin < S ? oin : S;
+    if constexpr (SM > 4) {   // a list of 16 keys is 32 registers: it goes to memory now, not after the agent scan
+        if (active && !helper) {
+#pragma unroll
+            for (int k = 0; k < SM; ++k)
+                if (k >= sofs) p.obst_idx[((size_t)a * S + (k - sofs)) * N + i] = (unsigned short)key_index(okey[k]);
+        }
+    }
     CA_STAMP(13);
 
     // ---- agent neighbours (App. A.2): K nearest within neighbor_dist, ties -> lower index ----
@@ -327,9 +334,11 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
             if (k >= kofs) st_idx_t<CA_NBW16(BS)>(p.nb_idx, ((size_t)a * K + (k - kofs)) * N + i, key_index(nkey[k]));  // ids of <= 256 agents fit a byte
+        if constexpr (SM <= 4) {
 #pragma unroll
-        for (int k = 0; k < SM; ++k)
-            if (k >= sofs) p.obst_idx[((size_t)a * S + (k - sofs)) * N + i] = (unsigned short)key_index(okey[k]);
+            for (int k = 0; k < SM; ++k)
+                if (k >= sofs) p.obst_idx[((size_t)a * S + (k - sofs)) * N + i] = (unsigned short)key_index(okey[k]);
+        }
     }
     CA_STAMP(15);
     return false;

@@ -142,9 +142,19 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     CA_OSTAMP(0);
     if (tid < 32) { s_rays[tid] = p.rays[tid]; s_oct[tid] = p.oct[tid]; }
 
-    for (int t = tid; t < N; t += OBS_BS) {
-        const size_t qa = (size_t)a * N + t;
-        s_px[t] = p.pos_x[qa]; s_py[t] = p.pos_y[qa]; s_vx[t] = p.vel_x[qa]; s_vy[t] = p.vel_y[qa];
+    // Arenas of more than 256 agents (16-bit neighbour ids) are not staged: each of the arena's N / 16 workgroups would
+    // copy all N agents (C5: 32 workgroups x 8 KB, a quarter of a wave's cycles) to look up 16 x K of them -- the neighbours'
+    // positions and velocities are gathered from the arena's global arrays (L2-resident: the solve has just written them).
+    constexpr bool GATHER = NW16;
+    const float* gpx = p.pos_x + (size_t)a * N;
+    const float* gpy = p.pos_y + (size_t)a * N;
+    const float* gvx = p.vel_x + (size_t)a * N;
+    const float* gvy = p.vel_y + (size_t)a * N;
+    if constexpr (!GATHER) {
+        for (int t = tid; t < N; t += OBS_BS) {
+            const size_t qa = (size_t)a * N + t;
+            s_px[t] = p.pos_x[qa]; s_py[t] = p.pos_y[qa]; s_vx[t] = p.vel_x[qa]; s_vy[t] = p.vel_y[qa];
+        }
     }
     int nn = 0, ns = 0;
     float c = 1.0f, s = 0.0f;
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
 
     const int M = 8 * nn + ns;
     float mx = 0.0f, my = 0.0f;
-    if (M > 0) { mx = s_px[i]; my = s_py[i]; }
+    if (M > 0) { mx = GATHER ? gpx[i] : s_px[i]; my = GATHER ? gpy[i] : s_py[i]; }
     if (r == 0) s_frame[g] = make_float4(c, s, mx, my);  // phase A lanes also work for the workgroup's other agents
     // ---- pre-pass: which (source, ray) pairs are worth the exact test?  Supersets only; never results. ----
     // (1) lane per agent NEIGHBOUR: all 8 octagon vertices lie on the circle of radius R around it, so the
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         int i0 = 0, w = 0;
         if (k < nn) {
             const int nb = s_nb[g * 16 + k];
-            const float rx = s_px[nb] - mx, ry = s_py[nb] - my;
+            const float rx = (GATHER ? gpx[nb] : s_px[nb]) - mx, ry = (GATHER ? gpy[nb] : s_py[nb]) - my;
             s_rel[g * 16 + k] = make_float2(rx, ry);  // (env.py:288-289) for the pair trips and the winners
             const float d2 = rx * rx + ry * ry, R = p.radius;
             const float ax = c * rx - s * ry, ay = s * rx + c * ry;
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
             const float4 oc = reinterpret_cast<const float4*>(s_oct)[e];
             x1 = oc.x + rx; y1 = oc.y + ry;
             x2 = oc.z + rx; y2 = oc.w + ry;
-            if (want_vel) { const int nb = s_nb[g * 16 + k]; vx = s_vx[nb]; vy = s_vy[nb]; }  // env.py:252
+            if (want_vel) { const int nb = s_nb[g * 16 + k]; vx = GATHER ? gvx[nb] : s_vx[nb]; vy = GATHER ? gvy[nb] : s_vy[nb]; }  // env.py:252
         } else {
             const ObstDev o1 = load_obst(tab, s_ob[g * 16 + (m - 8 * nn)]);
             x1 = o1.px - mx; y1 = o1.py - my;

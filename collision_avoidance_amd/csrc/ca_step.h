@@ -28,18 +28,58 @@ __host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S, int ST = 
 //         of the C3 workload are all resident at once instead of taking 1.6 rounds at 10 per CU.
 typedef const __attribute__((address_space(4))) StepCold ColdK;  // the cold block through the constant address space
 
+// An agent with MORE obstacle neighbours than the register-line kernel has obstacle slots (ST): solved apart, by its own
+// lane alone, exactly as the contract says -- every half-plane built in order into one contiguous LDS table (the wave's LP3
+// pool is free at that point), LP2 over it; the caller runs LP3 on the same table with lp3_coop (stride 1) if LP2 fails.
+// RVO2 keeps every edge in range (env.py:249, 301-318), so the list capacity stays 16; in the reference's doorway and
+// "congested" worlds (14 edges) no agent-step of 3.8e5 sampled had more than four (profiles/r04_c_reference_worlds.txt),
+// which is what lets those worlds run on the register-line kernel.  Not inlined: the hot path's registers are not its.
+template <bool NW16>
+__device__ __noinline__ void solve_many_obstacles(float4* tbl, int MLX, const ObstDev* tab, const unsigned short* oidx, const void* nidx,
+                                                 int stride, int ocnt, int ncnt, const float* arena, int bs, V2 pos, V2 vel, V2 pref,
+                                                 float R, float invTO, float invT, float invDt, float max_speed) {
+    // (few enough arguments to travel in registers: one on the stack would give the whole kernel a scratch segment)
+    const float *ax = arena, *ay = arena + bs, *avx = arena + 2 * bs, *avy = arena + 3 * bs;  // the staged arena: px | py | vx | vy
+    LdsLines ls; ls.base = tbl; ls.stride = 1;
+    int nl = 0;
+    for (int s = 0; s < ocnt; ++s) {
+        const int e = ld_idx_t<true>(oidx, (size_t)s * (size_t)stride);
+        Line line;
+        auto covered = [&](V2 c1, V2 c2) {
+            for (int j = 0; j < nl; ++j) {
+                const Line M = ls.get(j);
+                if (det(c1 - M.point, M.dir) - invTO * R >= -EPS && det(c2 - M.point, M.dir) - invTO * R >= -EPS) return true;
+            }
+            return false;
+        };
+        if (obst_orca_line(tab, e, pos, vel, R, invTO, covered, line)) { ls.put(nl, line); ++nl; }
+    }
+    const int numObst = nl;
+    for (int k = 0; k < ncnt; ++k) {
+        const int j = ld_idx_t<NW16>(nidx, (size_t)k * (size_t)stride);
+        ls.put(nl, agent_orca_line(pos, vel, mk(ax[j], ay[j]), mk(avx[j], avy[j]), R, invT, invDt));
+        ++nl;
+    }
+    V2 nv = mk(0.0f, 0.0f);
+    const int fail = lp2(ls, nl, max_speed, pref, false, nv);
+    // lp3_coop's slot header; the caller reads the result (and whether LP3 is needed: fail < nl) from it
+    tbl[2 * MLX - 1] = make_float4(nv.x, nv.y, __int_as_float(nl | (numObst << 8) | (fail << 16)), 0.0f);
+}
+
 #ifndef CA_LB512
 #define CA_LB512 4   // waves per SIMD the 512-lane register-line kernel is built for (diagnostic: 2 = 256 VGPRs)
 #endif
 // HELP = 2: launched with 2 BS lanes, the upper half helps in the neighbour scan and ends (ca_nbr.h)
-template <int KMAX, int BS, int ST, bool FUSE, int HELP = 1>
+// SMX: capacity of the obstacle-neighbour list (S <= SMX).  SMX > ST (register lines): the rare agent with more than ST
+// obstacle neighbours is solved apart (solve_many_obstacles)
+template <int KMAX, int BS, int ST, bool FUSE, int HELP = 1, int SMX = (ST > 0 ? ST : SMAX)>
 __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1) void step_kernel(const StepArgs p) {
     extern __shared__ float4 smem4[];
     CA_PRIO_START();
     // FUSE: the neighbour search runs at the head of this kernel instead of in a launch of its own (one
     // drain/fill less per step, and its dispatch skew overlaps useful work).  A lane later reads back only the
     // lists of its own agent, which it wrote itself; the search's LDS arrays are not used again.
-    if constexpr (FUSE) { if (nbr_body<KMAX, BS, (ST > 0 ? ST : SMAX), HELP>(p)) return; }
+    if constexpr (FUSE) { if (nbr_body<KMAX, BS, SMX, HELP>(p)) return; }
     constexpr int ML = ST + KMAX;  // register slots (ST > 0)
     const int tid = threadIdx.x;
     const int P = p.P;
@@ -94,7 +134,7 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
     // workgroups of more than one wave carry more per-lane state: there the preferred velocity waits in the lane's LDS
     // slot too (it is needed by every LP1 and by the epilogue; kept in registers it was spilled to scratch memory and
     // reloaded 14 times inside LP2 -- tools/kernel_resources.py)
-    constexpr bool PARK_PREF = ST > 0 && BS > 64;
+    constexpr bool PARK_PREF = ST > 0 && (BS > 64 || SMX > ST);
     if constexpr (PARK_PREF) { reinterpret_cast<float*>(s_misc)[tid * 4 + 2] = pref.x; reinterpret_cast<float*>(s_misc)[tid * 4 + 3] = pref.y; }
     __syncthreads();
 
@@ -122,11 +162,15 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
         float4 L[ML];
         static_for<ML>([&](auto kc) __attribute__((always_inline)) { L[decltype(kc)::value] = make_float4(0.0f, 0.0f, 1.0f, 0.0f); });
         int no = 0;  // obstacle lines produced so far (slots [0, no))
+        // more obstacle neighbours than line slots (SMX > ST only): this lane sits the register path out and is solved below
+        const bool many = (SMX > ST) && active && ocnt > ST;
+        const bool fast = active && !many;
         {
             const float invTO = 1.0f / p.time_horizon_obst;
-            int e_next = (ocnt > 0) ? ld_idx_t<true>(obst_idx_s, ((size_t)a * S + 0) * N + i) : 0;
-            for (int s = 0; s < S; ++s) {
-                if (s < ocnt) {
+            int e_next = (fast && ocnt > 0) ? ld_idx_t<true>(obst_idx_s, ((size_t)a * S + 0) * N + i) : 0;
+            const int s_end = S < ST ? S : ST;
+            for (int s = 0; s < s_end; ++s) {
+                if (fast && s < ocnt) {
                     const int e = e_next;
                     if (s + 1 < ocnt) e_next = ld_idx_t<true>(obst_idx_s, ((size_t)a * S + (s + 1)) * N + i);
                     auto covered = [&](V2 c1, V2 c2) __attribute__((always_inline)) {
@@ -183,7 +227,7 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
             if constexpr (PARK_PREF) return mk(reinterpret_cast<const float*>(s_misc)[tid * 4 + 2], reinterpret_cast<const float*>(s_misc)[tid * 4 + 3]);
             else return pref;
         };
-        if (active) fail = lp2_reg<ML, ST>(L, no, ncnt, p.max_speed, opt_fn, nv);
+        if (fast) fail = lp2_reg<ML, ST>(L, no, ncnt, p.max_speed, opt_fn, nv);
         CA_STAMP(6);
         CA_PRIO_POINT(5);
         // ---- LP3 for the lanes whose LP2 was infeasible: they copy their lines into a slot of the
@@ -218,6 +262,39 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
                     const float4 h = hdr[rank];
                     nv = mk(h.x, h.y);
                     need = false;
+                }
+            }
+            if constexpr (SMX > ST) {   // the agents with more than ST obstacle neighbours, one at a time (rare by selection)
+                // (everything this stage needs is derived afresh from the lane id, the staged arena and the lists the lane
+                // wrote itself -- behind an opaque move, so that nothing of it lives in registers across the solve)
+                constexpr int MLX = SMX + KMAX;
+                static_assert(2 * MLX <= 2 * ML * POOL_SLOTS, "the single-agent table fits the wave's pool");
+                int tid_o = threadIdx.x;
+                asm volatile("" : "+v"(tid_o));
+                const int la_o = tid_o >> p.logP, i_o = tid_o & (P - 1);
+                const int a_o = p.a0 + work_block(p) * apb + la_o;
+                const bool act_o = (a_o < p.a1) && (i_o < N) && !arena_frozen(p, a_o);
+                const int cnts_o = act_o ? (int)p.counts[a_o * N + i_o] : 0;
+                unsigned long long om = __ballot((cnts_o >> 8) > ST);
+                while (om) {
+                    const int ln = __ffsll((long long)om) - 1;
+                    om &= om - 1ull;
+                    if ((tid_o & 63) == ln) {
+                        const ObstDev* tab_o = p.obst + (p.tab_off != nullptr ? p.tab_off[a_o] : 0);
+                        solve_many_obstacles<CA_NBW16(BS)>(pool, MLX, tab_o, obst_idx_s + (size_t)a_o * S * N + i_o,
+                                                           (const char*)nb_idx_s + ((size_t)a_o * K * N + i_o) * (CA_NBW16(BS) ? 2 : 1), N,
+                                                           cnts_o >> 8, cnts_o & 0xFF, s_px + (la_o << p.logP), BS,
+                                                           mk(s_px[tid_o], s_py[tid_o]), mk(s_vx[tid_o], s_vy[tid_o]), opt_fn(), p.radius,
+                                                           1.0f / p.time_horizon_obst, 1.0f / p.time_horizon, 1.0f / p.time_step, p.max_speed);
+                    }
+                    wave_lds_sync();
+                    const int hz = __float_as_int(pool[2 * MLX - 1].z);   // n | numObst << 8 | fail << 16 (wave-uniform read)
+                    if (((hz >> 16) & 0xFF) < (hz & 0xFF)) {               // LP2 failed: LP3 on the same table, four lanes
+                        lp3_coop(pool, MLX, 1, p.max_speed, 1);
+                        wave_lds_sync();
+                    }
+                    if ((tid_o & 63) == ln) { const float4 h = pool[2 * MLX - 1]; nv = mk(h.x, h.y); }
+                    wave_lds_sync();   // (the next such agent rewrites the table)
                 }
             }
         }

@@ -233,3 +233,45 @@ def test_separated_start_crowd_is_the_crowd_with_redrawn_overlaps():
     px, py = plain.get(o.FLD_POS_X).astype(np.float64), plain.get(o.FLD_POS_Y).astype(np.float64)
     dp = np.hypot(px[:, :, None] - px[:, None, :], py[:, :, None] - py[:, None, :]) + 10 * np.eye(N)[None]
     assert dp.min() < 1.0                                                  # the plain crowd does start with overlaps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,N,n_edges", [(5, 6, 12), (10, 12, 16), (5, 40, 14)])
+def test_small_world_with_many_edges_in_range_on_the_register_line_kernel(K, N, n_edges):
+    """Worlds of at most 16 edges run on the register-line solve kernel, which has four obstacle-line slots; an agent
+    with MORE obstacle neighbours than that (RVO2 keeps every edge in range, env.py:249, 301-318) is solved apart, exactly
+    (ca_step.h solve_many_obstacles).  Here nearly every agent is such an agent: a small round room (a clockwise n-gon of
+    radius 2.2, so its walls face inwards and most of them are within range of everybody), forced onto the lane kernel."""
+    import math
+    import os
+    from collision_avoidance_amd import _lib
+    R = 2.2 if N <= 12 else 2.8
+    room = [(5.0 + R * math.cos(-2 * math.pi * k / n_edges), 5.0 + R * math.sin(-2 * math.pi * k / n_edges)) for k in range(n_edges)]
+    p = H.scenario_params("crowd", N, max_neighbors=K, neighbor_dist=3.0)
+    lo, hi = 5.0 - 0.5 * R, 5.0 + 0.5 * R
+    p.update(spawn_x0=lo, spawn_x1=hi, spawn_y0=lo, spawn_y1=hi, goal_x0=lo, goal_x1=hi, goal_y0=lo, goal_y1=hi, done_mode=2, max_step=0)
+    old = os.environ.get("CA_QUAD")
+    os.environ["CA_QUAD"] = "0"     # (a batch this small would otherwise take the four-lanes kernel, which has its own 16-entry variant)
+    try:
+        A = 24
+        g = H.make_gpu(A, N, "crowd", p, seed=5, polys=[room])
+        e = H.make_oracle(A, N, "crowd", p, seed=5, polys=[room])
+    finally:
+        if old is None:
+            del os.environ["CA_QUAD"]
+        else:
+            os.environ["CA_QUAD"] = old
+    assert g.launch_info()["lanes_per_agent"] == 1 and g.S == n_edges
+    g.reset(); e.reset()                      # into the room
+    rng = np.random.RandomState(2)
+    many = 0
+    for s in range(60):
+        act = rng.uniform(-1.0, 1.0, (A, N)).astype(np.float32)
+        g.step(act, stats=True); e.step(act, flags=o.F_OBS | o.F_STATS)
+        many += int((e.get(o.FLD_OBST_COUNT) > 4).sum())
+        if s % 20 == 19:
+            H.assert_state_equal(g, e, "round room step %d" % s, obs=True, reward=True)
+    H.assert_stats_equal(g, e, "round room")
+    assert many > (0.3 if N <= 12 else 0.05) * 60 * A * N, many          # the stage was really exercised
+    assert g.stats()["obst_overflow"] == 0
+    g.close()
