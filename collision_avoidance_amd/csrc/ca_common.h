@@ -74,6 +74,10 @@ struct StepArgs {
     unsigned long long* dbg;  // CA_STAMPS diagnostic build only: [waves][16] phase cycle counts
     int n_obst, A, N, P, logP, K, S;
     int a0, a1;  // this launch covers arenas [a0, a1) (chunked launches on several streams)
+    // lane -> (arena slot of the workgroup, agent): arenas take P lanes each (P = power of two >= N: shift and mask), or --
+    // linv != 0: arenas within one wave whose N is not a power of two -- N lanes each, back to back (the reference env's own
+    // 10-agent arenas: six per wave instead of four); linv = ceil(2^16 / N), so that (lane * linv) >> 16 = lane / N
+    int LS, apb, linv;
     int T;       // quad kernel, ORCA-only mode: steps advanced by this launch (ca_quad.h); 1 otherwise
     uint32_t flags;
     float time_step, neighbor_dist, time_horizon, time_horizon_obst, radius, max_speed;
@@ -88,6 +92,11 @@ __device__ __forceinline__ int work_block(const StepArgs& p) { return p.order ? 
 #else
 __device__ __forceinline__ int work_block(const StepArgs&) { return (int)blockIdx.x; }
 #endif
+
+__device__ __forceinline__ void lane_slot(const StepArgs& p, int tid, int& la, int& i) {
+    if (p.linv) { la = (tid * p.linv) >> 16; i = tid - la * p.LS; }
+    else { la = tid >> p.logP; i = tid & (p.P - 1); }
+}
 
 // CA_F_FREEZE: arenas whose arena_done flag is set are left exactly as they are
 __device__ __forceinline__ bool arena_frozen(const StepArgs& p, int a) {

@@ -60,6 +60,8 @@ struct ca_env {
     StepCold* d_cold = nullptr;      // the epilogue's arguments (ca_common.h)
     int* d_order = nullptr;          // [grid] block order of the solve kernel (null: identity)
     int P = 1, logP = 0, BS = 64, grid = 1, K = 0, S = 1;
+    bool obs_dense_on = false;
+    int LS = 1, apb = 1, linv = 0;   // lanes per arena, arenas per workgroup, ceil(2^16 / LS) or 0 (ca_common.h StepArgs)
     int BSn = 64, grid_n = 1;  // the neighbour kernel's own workgroup size
     bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
     int ST = 0, KT = 16;  // solve-kernel variant: ST > 0 = register lines with ST obstacle slots; KT = KMAX
@@ -224,14 +226,17 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.reset_px = nullptr; a.reset_py = nullptr; a.reset_mask = nullptr; a.dbg = e->dbg;
     a.n_obst = e->h_tab_off.empty() ? (int)e->h_obst.size() : 0; a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
     a.K = e->K; a.S = e->S; a.flags = flags; a.a0 = 0; a.a1 = c.n_arenas; a.T = 1;
+    a.LS = e->LS; a.apb = e->apb; a.linv = e->linv;
     a.time_step = c.time_step; a.neighbor_dist = c.neighbor_dist; a.time_horizon = c.time_horizon;
     a.time_horizon_obst = c.time_horizon_obst; a.radius = c.radius; a.max_speed = c.max_speed;
 }
 
 template <int KMAX, int SM>
-static void launch_nbr_k(ca_env* e, const StepArgs& a) {
+static void launch_nbr_k(ca_env* e, const StepArgs& a_in) {
     const dim3 grid(e->grid_n), block(e->BSn);
     ProfScope ps(e, KIND_NBR);
+    StepArgs a = a_in;
+    a.apb = e->BSn / e->P;   // (the stand-alone neighbour kernel may run with a workgroup size of its own: CA_NBR_BS)
     switch (e->BSn) {
         case 64: launch_k(ps, nbr_kernel<KMAX, 64, SM>, grid, block, 0, e->stream, a); break;
         case 128: launch_k(ps, nbr_kernel<KMAX, 128, SM>, grid, block, 0, e->stream, a); break;
@@ -346,6 +351,11 @@ static obs_fn_t obs_fn(int obs_bs, bool w16) {  // workgroup size x width of the
     }
 }
 
+// Arenas of fewer than 16 agents: the 16 agent groups of an observation workgroup take 16 consecutive agents of the batch (the
+// reference env's own 10-agent arenas would otherwise leave 6 of 16 groups idle).  CA_OBS_DENSE=0: one arena per workgroup.
+static bool obs_dense(const ca_env* e) { return e->obs_dense_on; }   // (latched by ca_create)
+static int obs_nstage(const ca_env* e) { return obs_dense(e) ? 16 + 2 * e->cfg.n_agents : e->cfg.n_agents; }
+
 static hipError_t launch_obs(ca_env* e) {
     if (!e->orient_valid) {  // positions or goals were edited from outside: re-derive the frame
         StepArgs a;
@@ -367,12 +377,14 @@ static hipError_t launch_obs(ca_env* e) {
     o.bpa = (o.N + apb - 1) / apb;
     o.paircap = 16 * (e->K + e->S);
     o.a0 = 0; o.dbg = e->dbg_obs;
-    o.xcd = o.A % 8 == 0 ? 1 : 0;  // the arena's observation on the XCD (workgroup index mod 8) whose solve workgroup wrote its state
+    o.dense = obs_dense(e) ? 1 : 0;
+    o.nstage_max = obs_nstage(e);
+    o.xcd = (o.A % 8 == 0 && !o.dense) ? 1 : 0;  // the arena's observation on the XCD (workgroup index mod 8) whose solve workgroup wrote its state
     o.radius = e->cfg.radius;
     memcpy(o.rays, e->rays, sizeof o.rays);
     memcpy(o.oct, e->oct, sizeof o.oct);
-    const dim3 grid((unsigned)((size_t)o.A * o.bpa)), block(obs_bs);
-    const size_t lds = obs_lds_bytes(o.N, obs_bs, o.paircap);
+    const dim3 grid(o.dense ? (unsigned)(((size_t)o.A * o.N + apb - 1) / apb) : (unsigned)((size_t)o.A * o.bpa)), block(obs_bs);
+    const size_t lds = obs_lds_bytes(o.nstage_max, obs_bs, o.paircap);
     ProfScope ps(e, KIND_OBS);
     launch_k(ps, obs_fn(obs_bs, e->nidx16 != 0), grid, block, lds, e->stream, o);
     return hipGetLastError();
@@ -592,8 +604,8 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     while (P < cfg->n_agents) { P <<= 1; ++logP; }
     e->P = P; e->logP = logP;
     e->BS = P > 64 ? P : 64;
-    const int apb = e->BS / P;
-    e->grid = (cfg->n_arenas + apb - 1) / apb;
+    e->LS = P; e->apb = e->BS / P; e->linv = 0;
+    e->grid = (cfg->n_arenas + e->apb - 1) / e->apb;
     {
         const char* v = getenv("CA_NBR_BS");  // diagnostic switch: power of two in [max(P, 64), 1024]
         const int want = v ? atoi(v) : 0;
@@ -603,6 +615,24 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->grid_n = (cfg->n_arenas + e->BSn / P - 1) / (e->BSn / P);
         const char* f = getenv("CA_FUSE_NBR");  // diagnostic switch: 0 = separate neighbour kernel
         e->fuse_nbr = !(f && f[0] == '0') && e->BSn == e->BS;
+    }
+    {
+        const char* v = getenv("CA_OBS_DENSE");  // diagnostic switch: 0 = one arena per observation workgroup
+        e->obs_dense_on = cfg->n_agents < 16 && !(v && v[0] == '0');
+    }
+    {   // arenas within one wave whose N is no power of two: N lanes each, back to back, where that packs more arenas into the
+        // wave than P lanes each (the reference env's own 10-agent arenas: six per wave instead of four)
+        const char* v = getenv("CA_DENSE");  // diagnostic switch: 0 = P lanes per arena
+        const int N = cfg->n_agents;
+        if (!(v && v[0] == '0') && e->fuse_nbr && e->BS == 64 && P < 64 && 64 / N > 64 / P) {
+            const int linv = (65536 + N - 1) / N;
+            bool exact = true;
+            for (int t = 0; t < 64; ++t) exact = exact && ((t * linv) >> 16) == t / N;
+            if (exact) {
+                e->LS = N; e->apb = 64 / N; e->linv = linv;
+                e->grid = (cfg->n_arenas + e->apb - 1) / e->apb;
+            }
+        }
     }
     e->K = cfg->max_neighbors;
     e->S = cfg->max_obst_neighbors;
@@ -615,7 +645,8 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         // (register budget: a 1024-lane workgroup caps the kernel at 128 VGPRs, a 512-lane one at 256 -- the variant with 16
         // obstacle neighbours and K = 10 needs all 256 already at 256 lanes)
         const bool fits = e->K <= 10 && 4 * P <= ((e->SQ == 16 && e->KT == 10) ? 256 : 512);
-        const long lane_waves = (long)e->grid * (e->BS / 64);
+        // (counted at P lanes per arena, the layout the crossover was measured with, whatever the packing is now)
+        const long lane_waves = (long)((cfg->n_arenas + e->BS / P - 1) / (e->BS / P)) * (e->BS / 64);
         e->quad = fits && (v ? v[0] == '1' : lane_waves < 1024);
         e->quad_roll = fits && (v ? v[0] == '1' : lane_waves <= 1024);  // T steps per launch: ahead at 1024 lane-waves too
         e->BSq = 4 * P > 64 ? 4 * P : 64;
@@ -661,7 +692,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         r = hipFuncSetAttribute(quad_fn(e), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_q);
     if (r == hipSuccess) {
         const int obs_bs = obs_block_threads(cfg->n_agents);
-        const size_t ol = obs_lds_bytes(cfg->n_agents, obs_bs, 16 * (e->K + e->S));
+        const size_t ol = obs_lds_bytes(obs_nstage(e), obs_bs, 16 * (e->K + e->S));
         if (ol > 48 * 1024) {
             r = hipFuncSetAttribute(reinterpret_cast<const void*>(obs_fn(obs_bs, e->nidx16 != 0)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ol);
@@ -1392,7 +1423,8 @@ int ca_launch_info(ca_env* e, int32_t* block, int32_t* grid, int32_t* lds_bytes,
     if (lds_bytes) *lds_bytes = (int32_t)(e->quad ? e->lds_q : (e->pair ? e->lds_p : e->lds));
     if (obs_grid) {
         const int apb = obs_block_threads(e->cfg.n_agents) / 16;
-        *obs_grid = (int32_t)((size_t)e->cfg.n_arenas * ((e->cfg.n_agents + apb - 1) / apb));
+        *obs_grid = obs_dense(e) ? (int32_t)(((size_t)e->cfg.n_arenas * e->cfg.n_agents + apb - 1) / apb)
+                                 : (int32_t)((size_t)e->cfg.n_arenas * ((e->cfg.n_agents + apb - 1) / apb));
     }
     return CA_OK;
 }

@@ -69,14 +69,14 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
     const bool helper = HELP > 1 && tid0 >= BS;   // (whole waves: BS is a multiple of 64)
     const int tid = helper ? tid0 - BS : tid0;    // the agent slot this lane works for
     const int P = p.P;
-    const int la = tid >> p.logP;
-    const int i = tid & (P - 1);
-    const int apb = BS >> p.logP;
+    int la, i;
+    lane_slot(p, tid, la, i);
+    const int apb = p.apb;
     const int a = p.a0 + work_block(p) * apb + la;
-    const bool active = (a < p.a1) && (i < p.N) && !arena_frozen(p, a);
+    const bool active = (a < p.a1) && (i < p.N) && (la < apb) && !arena_frozen(p, a);
     const int N = p.N, K = p.K, S = p.S;
     const int q = active ? a * N + i : 0;
-    const int lbase = la << p.logP;
+    const int lbase = tid - i;
     CA_STAMP(12);
     V2 pos = mk(0.0f, 0.0f);
     if (active && !helper) pos = mk(p.pos_x[q], p.pos_y[q]);

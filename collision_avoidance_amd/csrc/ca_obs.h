@@ -31,9 +31,12 @@ struct ObsArgs {
     const int* tab_off;                 // null or [A + 1]: per-arena edge tables (see StepArgs)
     float* obs;
     int A, N, K, S, bpa;  // bpa = workgroups per arena = ceil(N / 16)
+    int nstage_max;       // entries of the staged position / velocity arrays (sizes the LDS carve-up)
     int paircap;          // entries of an agent's (source, ray) pair list: 16 rays x (K + S) sources
     int a0;               // first arena of this launch
     int xcd;              // 1: workgroup b serves an arena with (arena - a0) % 8 == b % 8, i.e. on the XCD whose solve wave wrote it
+    int dense;            // 1 (arenas of fewer than 16 agents): a workgroup's 16 agent groups are 16 CONSECUTIVE agents of the batch,
+                          // whatever arenas they belong to -- the reference env's own 10-agent arenas fill 16 of 16 groups instead of 10
     unsigned long long* dbg;  // CA_STAMPS diagnostic build only: [waves][16] phase time stamps
     float radius;         // of the octagon = agent radius (env.py:31,338)
     float rays[32];       // env.py:321-332
@@ -60,9 +63,9 @@ struct ObsArgs {
 //              | ray and octagon tables [64] | pair counts [2][16] | (source, ray) pairs [16 x 16 (K + S)] u16: the
 //              workgroup's (agent, neighbour, ray) list from the front, every agent's obstacle pairs in a block of its
 //              own from the back
-__host__ __device__ inline size_t obs_lds_bytes(int N, int obs_bs, int paircap) {
+__host__ __device__ inline size_t obs_lds_bytes(int nstage_max, int obs_bs, int paircap) {
     const size_t apb = obs_bs / 16;
-    return (size_t)N * 16 + 2 * apb * 16 * 8 + apb * 16 + apb * 16 * 4 + apb * 16 * 4 + 64 * 4 + 2 * apb * 4 + apb * (size_t)paircap * 2;
+    return (size_t)nstage_max * 16 + 2 * apb * 16 * 8 + apb * 16 + apb * 16 * 4 + apb * 16 * 4 + 64 * 4 + 2 * apb * 4 + apb * (size_t)paircap * 2;
 }
 #ifndef CA_OBS_BS_MAX
 #define CA_OBS_BS_MAX 256
@@ -117,18 +120,33 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     // read sits in that XCD's L2 (C3: obs_kernel 62.2 -> 61.5 us).
     int bid = blockIdx.x;
     if (p.xcd) { const int x = bid & 7, idx = bid >> 3, q8 = idx / p.bpa; bid = (x + 8 * q8) * p.bpa + (idx - q8 * p.bpa); }
-    const int ab = bid / p.bpa;
-    const int a = p.a0 + ab;
-    const int i = (bid - ab * p.bpa) * OBS_APB + g;
-    const bool active = i < N;
+    int a, i, a_lo, nstage;   // this group's arena and agent; first arena and number of agents the workgroup stages
+    bool active;
+    if (p.dense) {   // groups = consecutive agents of the batch
+        const int first = bid * OBS_APB, gi = first + g;
+        active = gi < p.A * N;
+        const int ga = active ? gi : p.A * N - 1;
+        a = p.a0 + ga / N; i = ga - (ga / N) * N;
+        a_lo = p.a0 + first / N;
+        const int last = min(first + OBS_APB - 1, p.A * N - 1);
+        nstage = (last / N - first / N + 1) * N;
+    } else {
+        const int ab = bid / p.bpa;
+        a = p.a0 + ab;
+        i = (bid - ab * p.bpa) * OBS_APB + g;
+        active = i < N;
+        a_lo = a; nstage = N;
+    }
+    const int abase = (a - a_lo) * N;   // LDS index of agent 0 of this group's arena
     const size_t q = (size_t)a * N + (active ? i : 0);
     const ObstDev* tab = p.obst + (p.tab_off ? p.tab_off[a] : 0);  // this arena's edge table
 
+    const int NST = p.nstage_max;   // agents staged at most (N; dense: up to 16 + 2 N)
     float* s_px = reinterpret_cast<float*>(smem4);
-    float* s_py = s_px + N;
-    float* s_vx = s_py + N;
-    float* s_vy = s_vx + N;
-    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_vy + N);  // N*16 B: 8-aligned
+    float* s_py = s_px + NST;
+    float* s_vx = s_py + NST;
+    float* s_vy = s_vx + NST;
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_vy + NST);  // NST*16 B: 8-aligned
     float2* s_rel = reinterpret_cast<float2*>(s_key + OBS_APB * 16);             // neighbour slot k of agent g: p_nb - p_g
     float4* s_frame = reinterpret_cast<float4*>(s_rel + OBS_APB * 16);           // (cos, sin, pos x, pos y) per agent
     int* s_nb = reinterpret_cast<int*>(s_frame + OBS_APB);
@@ -151,8 +169,8 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     const float* gvx = p.vel_x + (size_t)a * N;
     const float* gvy = p.vel_y + (size_t)a * N;
     if constexpr (!GATHER) {
-        for (int t = tid; t < N; t += OBS_BS) {
-            const size_t qa = (size_t)a * N + t;
+        for (int t = tid; t < nstage; t += OBS_BS) {   // (the staged arenas are contiguous in memory)
+            const size_t qa = (size_t)a_lo * N + t;
             s_px[t] = p.pos_x[qa]; s_py[t] = p.pos_y[qa]; s_vx[t] = p.vel_x[qa]; s_vy[t] = p.vel_y[qa];
         }
     }
@@ -162,7 +180,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         const int cnts = p.counts[q];
         nn = cnts & 0xFF; ns = cnts >> 8;
         c = p.orient_x[q]; s = -p.orient_y[q];  // utils.py:48-51: cos/sin of -atan2(orientation)
-        if (r < nn) s_nb[g * 16 + r] = ld_idx_t<NW16>(p.nb_idx, ((size_t)a * K + r) * N + i);
+        if (r < nn) s_nb[g * 16 + r] = (GATHER ? 0 : abase) + ld_idx_t<NW16>(p.nb_idx, ((size_t)a * K + r) * N + i);  // as an index of the staged arrays
         if (r < ns) s_ob[g * 16 + r] = (int)p.obst_idx[((size_t)a * S + r) * N + i];
     }
     s_key[g * 16 + r] = ~0ull;
@@ -173,7 +191,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
 
     const int M = 8 * nn + ns;
     float mx = 0.0f, my = 0.0f;
-    if (M > 0) { mx = GATHER ? gpx[i] : s_px[i]; my = GATHER ? gpy[i] : s_py[i]; }
+    if (M > 0) { mx = GATHER ? gpx[i] : s_px[abase + i]; my = GATHER ? gpy[i] : s_py[abase + i]; }
     if (r == 0) s_frame[g] = make_float4(c, s, mx, my);  // phase A lanes also work for the workgroup's other agents
     // ---- pre-pass: which (source, ray) pairs are worth the exact test?  Supersets only; never results. ----
     // (1) lane per agent NEIGHBOUR: all 8 octagon vertices lie on the circle of radius R around it, so the

@@ -83,16 +83,16 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
     constexpr int ML = ST + KMAX;  // register slots (ST > 0)
     const int tid = threadIdx.x;
     const int P = p.P;
-    const int la = tid >> p.logP;
-    const int i = tid & (P - 1);
-    const int apb = BS >> p.logP;
+    int la, i;
+    lane_slot(p, tid, la, i);
+    const int apb = p.apb;
     const int a = p.a0 + work_block(p) * apb + la;
     const bool frozen = arena_frozen(p, a);  // CA_F_FREEZE: the episode of this arena is over
-    const bool active = (a < p.a1) && (i < p.N) && !frozen;
+    const bool active = (a < p.a1) && (i < p.N) && (la < apb) && !frozen;
     if (frozen && i == 0) p.arena_stats[(size_t)a * ST_STRIDE + ST_FROZEN] += 1;
     const int N = p.N, K = p.K, S = p.S;
     const int q = active ? a * N + i : 0;
-    const int lbase = la << p.logP;
+    const int lbase = tid - i;   // the arena's first lane (= its first slot of the staged arrays)
 
     float4* s_lines = smem4;  // ST = 0: [(K+S)][BS];  ST > 0: [waves][2 ML][POOL_SLOTS] (last row: slot headers)
     float* s_px = reinterpret_cast<float*>(
@@ -271,9 +271,10 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
                 static_assert(2 * MLX <= 2 * ML * POOL_SLOTS, "the single-agent table fits the wave's pool");
                 int tid_o = threadIdx.x;
                 asm volatile("" : "+v"(tid_o));
-                const int la_o = tid_o >> p.logP, i_o = tid_o & (P - 1);
+                int la_o, i_o;
+                lane_slot(p, tid_o, la_o, i_o);
                 const int a_o = p.a0 + work_block(p) * apb + la_o;
-                const bool act_o = (a_o < p.a1) && (i_o < N) && !arena_frozen(p, a_o);
+                const bool act_o = (a_o < p.a1) && (i_o < N) && (la_o < apb) && !arena_frozen(p, a_o);
                 const int cnts_o = act_o ? (int)p.counts[a_o * N + i_o] : 0;
                 unsigned long long om = __ballot((cnts_o >> 8) > ST);
                 while (om) {
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
                         const ObstDev* tab_o = p.obst + (p.tab_off != nullptr ? p.tab_off[a_o] : 0);
                         solve_many_obstacles<CA_NBW16(BS)>(pool, MLX, tab_o, obst_idx_s + (size_t)a_o * S * N + i_o,
                                                            (const char*)nb_idx_s + ((size_t)a_o * K * N + i_o) * (CA_NBW16(BS) ? 2 : 1), N,
-                                                           cnts_o >> 8, cnts_o & 0xFF, s_px + (la_o << p.logP), BS,
+                                                           cnts_o >> 8, cnts_o & 0xFF, s_px + (tid_o - i_o), BS,
                                                            mk(s_px[tid_o], s_py[tid_o]), mk(s_vx[tid_o], s_vy[tid_o]), opt_fn(), p.radius,
                                                            1.0f / p.time_horizon_obst, 1.0f / p.time_horizon, 1.0f / p.time_step, p.max_speed);
                     }
@@ -368,11 +369,11 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
     // pointer came from and would use per-lane flat loads)
     const ColdK& c = *(ColdK*)cold_e;
     const int tid = tid_e;
-    const int la = tid >> p.logP;
-    const int i = tid & (P - 1);
+    int la, i;
+    lane_slot(p, tid, la, i);
     const int a = p.a0 + work_block(p) * apb + la;
     const int q = active ? a * N + i : 0;
-    const int lbase = la << p.logP;
+    const int lbase = tid - i;
     const ObstDev* tab = p.obst + ((p.tab_off != nullptr && active) ? p.tab_off[a] : 0);
     pf32 = mk(reinterpret_cast<float*>(s_misc)[tid * 4 + 0], reinterpret_cast<float*>(s_misc)[tid * 4 + 1]);
     if constexpr (PARK_PREF) pref = mk(reinterpret_cast<float*>(s_misc)[tid * 4 + 2], reinterpret_cast<float*>(s_misc)[tid * 4 + 3]);
@@ -521,7 +522,9 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
     if (p.actions && (p.flags & 2u)) {
         double r = active ? (double)rew : 0.0;
         const int w = P < 64 ? P : 64;
-        for (int off = w >> 1; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
+        // (the guard keeps the tree inside the arena where arenas are packed back to back -- N lanes each, N no power of two;
+        // a no-op where an arena has P lanes and the lanes beyond N hold zeros)
+        for (int off = w >> 1; off > 0; off >>= 1) { const double t = __shfl_down(r, off, 64); if (p.linv == 0 || i + off < N) r += t; }
         if (active && (i & 63) == 0)
             atomicAdd(reinterpret_cast<double*>(&c.arena_stats[(size_t)a * ST_STRIDE + ST_SUMREW]), r);
     }
