@@ -49,6 +49,17 @@ struct StepCold {
     float spawn_x0, spawn_x1, spawn_y0, spawn_y1, goal_x0, goal_x1, goal_y0, goal_y1;
 };
 
+// ALAN online learning inside the four-lanes kernel (ca_quad.h): the bandit's arguments, in device memory like StepCold
+// (written by ca_alan_configure)
+struct AlanCold {
+    double *w, *t;          // [A][nA][N] action weights / time since the action's weight was set
+    int* action;            // [A*N] the action of the last step
+    float* reward;          // [A*N]
+    double act_c[32], act_s[32];  // (cos, sin) of every action's angle
+    double temp, window, dt, reward_scale;
+    int nA;
+};
+
 struct StepArgs {
     const float *pos_x, *pos_y, *vel_x, *vel_y, *pref_x, *pref_y;
     const double *goal_x, *goal_y;
@@ -67,6 +78,8 @@ struct StepArgs {
 #ifdef CA_STAMPS
     const int* order;      // diagnostic build only: null, or [blocks]: workgroup b works on the arenas of block order[b]
 #endif
+    const AlanCold* alan;  // four-lanes kernel, ALAN instantiation: the bandit around every step (ALAN:569-628); else unused
+    const double* alan_u;  // ... caller-supplied uniforms [A*N] of a single step, or null: the counter-based RNG
     const float* actions;  // null: orca_step
     const float* reset_px; // explicit reset positions (reset kernel only)
     const float* reset_py;

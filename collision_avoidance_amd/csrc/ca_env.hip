@@ -49,6 +49,8 @@ struct ca_env {
     // [A*N][4] fp64 directions of the step in flight
     double *alan_w = nullptr, *alan_t = nullptr, *alan_dirs = nullptr, *alan_u = nullptr;
     int* alan_action = nullptr;
+    AlanCold* d_alan = nullptr;
+    bool alan_fused = false;      // ca_alan_step / ca_alan_rollout run as ONE launch of the four-lanes kernel   // the bandit's arguments for the four-lanes kernel (ca_common.h)
     int* mask_buf = nullptr;  // staging for ca_reset_masked's host mask
     int n_actions = 0;
     double act_c[CA_ALAN_MAX_ACTIONS], act_s[CA_ALAN_MAX_ACTIONS];
@@ -219,7 +221,7 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.pref_x = e->pref_x; a.pref_y = e->pref_y; a.goal_x = e->goal_x; a.goal_y = e->goal_y;
     a.counts = e->counts; a.nb_idx = e->nb_idx; a.obst_idx = e->obst_idx;
     a.arena_done = e->arena_done; a.arena_stats = e->arena_stats; a.cold = e->d_cold;
-    a.obst = e->d_obst; a.tab_off = e->d_tab_off; a.actions = actions;
+    a.obst = e->d_obst; a.tab_off = e->d_tab_off; a.actions = actions; a.alan = nullptr; a.alan_u = nullptr;
 #ifdef CA_STAMPS
     a.order = e->fuse_nbr ? e->d_order : nullptr;  // (the order is sized for the solve kernel's grid)
 #endif
@@ -287,29 +289,35 @@ template <int KMAX, int ST>
 static hipError_t launch_step_k(ca_env* e, const StepArgs& a) {
     return e->fuse_nbr ? launch_step_kf<KMAX, ST, true>(e, a) : launch_step_kf<KMAX, ST, false>(e, a);
 }
-template <int KMAX, int SQ>
+template <int KMAX, int SQ, bool ALAN>
 static const void* quad_fn_k(int BS) {
     switch (BS) {
-        case 64: return reinterpret_cast<const void*>(&quad_kernel<KMAX, 64, SQ>);
-        case 128: return reinterpret_cast<const void*>(&quad_kernel<KMAX, 128, SQ>);
-        case 256: return reinterpret_cast<const void*>(&quad_kernel<KMAX, 256, SQ>);
-        default: return reinterpret_cast<const void*>(&quad_kernel<KMAX, 512, SQ>);
+        case 64: return reinterpret_cast<const void*>(&quad_kernel<KMAX, 64, SQ, ALAN>);
+        case 128: return reinterpret_cast<const void*>(&quad_kernel<KMAX, 128, SQ, ALAN>);
+        case 256: return reinterpret_cast<const void*>(&quad_kernel<KMAX, 256, SQ, ALAN>);
+        default: return reinterpret_cast<const void*>(&quad_kernel<KMAX, 512, SQ, ALAN>);
     }
 }
-static const void* quad_fn(const ca_env* e) {
-    if (e->KT == 5) return e->SQ == 4 ? quad_fn_k<5, 4>(e->BSq) : quad_fn_k<5, 16>(e->BSq);
-    return e->SQ == 4 ? quad_fn_k<10, 4>(e->BSq) : quad_fn_k<10, 16>(e->BSq);
+static const void* quad_fn(const ca_env* e, bool alan = false) {
+    if (alan) {
+        if (e->KT == 5) return e->SQ == 4 ? quad_fn_k<5, 4, true>(e->BSq) : quad_fn_k<5, 16, true>(e->BSq);
+        return e->SQ == 4 ? quad_fn_k<10, 4, true>(e->BSq) : quad_fn_k<10, 16, true>(e->BSq);
+    }
+    if (e->KT == 5) return e->SQ == 4 ? quad_fn_k<5, 4, false>(e->BSq) : quad_fn_k<5, 16, false>(e->BSq);
+    return e->SQ == 4 ? quad_fn_k<10, 4, false>(e->BSq) : quad_fn_k<10, 16, false>(e->BSq);
 }
 // neighbour search + lines + LP + integration + reward/done, four lanes per agent, a.T steps
 static hipError_t launch_quad(ca_env* e, const StepArgs& a) {
     ProfScope ps(e, KIND_STEP, a.T > 1 ? a.T : 1);
     StepArgs arg = a;
     void* params[] = {&arg};
-    if (ps.t0) return hipExtLaunchKernel(quad_fn(e), dim3(e->grid_q), dim3(e->BSq), params, e->lds_q, e->stream, ps.t0, ps.t1, 0);
-    return hipLaunchKernel(quad_fn(e), dim3(e->grid_q), dim3(e->BSq), params, e->lds_q, e->stream);
+    const bool alan = a.alan != nullptr;   // the bandit inside the launch (ca_alan_step / ca_alan_rollout)
+    const size_t lds = alan ? quad_lds_bytes(e->BSq, e->KT, e->SQ, e->n_actions) : e->lds_q;
+    if (ps.t0) return hipExtLaunchKernel(quad_fn(e, alan), dim3(e->grid_q), dim3(e->BSq), params, lds, e->stream, ps.t0, ps.t1, 0);
+    return hipLaunchKernel(quad_fn(e, alan), dim3(e->grid_q), dim3(e->BSq), params, lds, e->stream);
 }
 static hipError_t launch_step(ca_env* e, const StepArgs& a) {
-    if (e->quad || (a.T > 1 && e->quad_roll)) return launch_quad(e, a);
+    if (e->quad || (a.T > 1 && e->quad_roll) || a.alan != nullptr) return launch_quad(e, a);
     if (e->ST > 0) return e->KT == 5 ? launch_step_k<5, 4>(e, a) : launch_step_k<10, 4>(e, a);
     if (e->K <= 5) return launch_step_k<5, 0>(e, a);
     if (e->K <= 10) return launch_step_k<10, 0>(e, a);
@@ -723,7 +731,7 @@ int ca_destroy(ca_env* e) {
                     e->agent_done, e->arrive_step,
                     e->regoal_count, e->counts, e->nb_idx, e->obst_idx, e->cvt_buf, e->d_tab_off, e->d_cold, e->d_order, e->step_count,
                     e->arena_done, e->episode, e->arena_stats, e->arena_steps, e->d_obst, e->dbg, e->dbg_obs,
-                    e->alan_w, e->alan_t, e->alan_dirs, e->alan_u, e->alan_action, e->mask_buf};
+                    e->alan_w, e->alan_t, e->alan_dirs, e->alan_u, e->alan_action, e->d_alan, e->mask_buf};
     for (void* b : bufs) if (b) hipFree(b);
     if (e->obs && !e->obs_external) hipFree(e->obs);
     for (const ca_env::Span& sp : e->spans) { hipEventDestroy(sp.t0); hipEventDestroy(sp.t1); }
@@ -1201,6 +1209,20 @@ int ca_alan_configure(ca_env* e, const double* actions_xy, int32_t n_actions, do
     }
     e->n_actions = n_actions;
     e->alan_temp = temp; e->alan_window = timewindow; e->alan_dt = time_step;
+    {   // the same arguments for the four-lanes kernel, which runs the bandit inside its launch (ca_quad.h)
+        if (!e->d_alan) HIPCHK(e, hipMalloc((void**)&e->d_alan, sizeof(AlanCold)));
+        AlanCold h;
+        memset(&h, 0, sizeof h);
+        h.w = e->alan_w; h.t = e->alan_t; h.action = e->alan_action; h.reward = e->reward;
+        memcpy(h.act_c, e->act_c, sizeof h.act_c); memcpy(h.act_s, e->act_s, sizeof h.act_s);
+        h.temp = temp; h.window = timewindow; h.dt = time_step; h.reward_scale = e->cfg.reward_scale; h.nA = n_actions;
+        HIPCHK(e, upload(e, e->d_alan, &h, sizeof h));
+        const size_t lq = quad_lds_bytes(e->BSq, e->KT, e->SQ, n_actions);
+        const char* fv = getenv("CA_ALAN_FUSED");   // diagnostic switch: 0 = the three-launch form everywhere
+        e->alan_fused = (e->quad || e->quad_roll) && lq <= 64 * 1024 && !(fv && fv[0] == '0');
+        if (e->alan_fused && lq > 48 * 1024)
+            HIPCHK(e, hipFuncSetAttribute(quad_fn(e, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq));
+    }
     return CA_OK;
 }
 
@@ -1216,6 +1238,16 @@ int ca_alan_step(ca_env* e, const double* u, int32_t u_is_device, uint32_t flags
         u = e->alan_u;
     }
     if (e->prof_period > 1) e->profiling = (e->steps_done % (uint64_t)e->prof_period) == 0;
+    if (e->alan_fused && e->quad) {   // ONE launch: the bandit runs inside the four-lanes kernel (ca_quad.h)
+        StepArgs a;
+        fill_args(e, a, nullptr, flags);
+        a.alan = e->d_alan; a.alan_u = u;
+        HIPCHK(e, launch_step(e, a));
+        e->orient_valid = true;
+        if (flags & CA_F_OBS) HIPCHK(e, launch_obs(e));
+        e->steps_done += 1;
+        return CA_OK;
+    }
     const ca_config& c = e->cfg;
     AlanArgs p;
     p.pos_x = e->pos_x; p.pos_y = e->pos_y; p.vel_x = e->vel_x; p.vel_y = e->vel_y;
@@ -1249,6 +1281,22 @@ int ca_alan_step(ca_env* e, const double* u, int32_t u_is_device, uint32_t flags
 
 int ca_alan_rollout(ca_env* e, int32_t steps, uint32_t flags) {
     if (!e || steps < 0) return fail(e, CA_EINVAL, "ca_alan_rollout: bad argument");
+    if (e->n_actions > 0 && e->alan_fused && e->quad_roll && !(flags & (CA_F_OBS | CA_F_AUTORESET | CA_F_NODONE)) && steps > 1) {
+        // run_sim(mode=1) (ALAN:106-123) as ONE launch per CA_ROLLOUT_MAX_T steps: select -> doStep -> update for every step
+        // inside the four-lanes kernel, weights and times resident in LDS (ca_quad.h)
+        HIPCHK(e, hipSetDevice(e->device));
+        StepArgs a;
+        fill_args(e, a, nullptr, flags);
+        a.alan = e->d_alan;
+        for (int done = 0; done < steps; done += CA_ROLLOUT_MAX_T) {
+            if (e->prof_period > 1) e->profiling = (e->steps_done / (uint64_t)CA_ROLLOUT_MAX_T) % (uint64_t)e->prof_period == 0;
+            a.T = steps - done < CA_ROLLOUT_MAX_T ? steps - done : CA_ROLLOUT_MAX_T;
+            HIPCHK(e, launch_step(e, a));
+            e->steps_done += (uint64_t)a.T;
+        }
+        e->orient_valid = true;
+        return CA_OK;
+    }
     for (int s = 0; s < steps; ++s) {
         const int rc = ca_alan_step(e, nullptr, 0, flags);
         if (rc) return rc;

@@ -29,6 +29,7 @@
 // wave (CA_QUAD=0/1 forces it).
 #pragma once
 #include "ca_step.h"
+#include "ca_alan.h"
 
 namespace ca {
 
@@ -156,14 +157,20 @@ __device__ __forceinline__ int lp2_quad(const LdsLines& ls, int n, int q, float 
 
 // LDS of the quad kernel (bytes): line table [waves][2 ML][16] float4 | px py vx vy [BS/4] | per-arena reductions
 // [BS/4][4] int | rewards [BS/4] double
-__host__ __device__ inline size_t quad_lds_bytes(int BS, int KMAX, int SQ) {
+// (+ ALAN instantiation: weights | times | softmax terms, [n_actions][BS/4] doubles each)
+__host__ __device__ inline size_t quad_lds_bytes(int BS, int KMAX, int SQ, int n_actions = 0) {
     const size_t ns = (size_t)BS / 4;
-    return (size_t)(BS / 64) * (2 * (SQ + KMAX)) * POOL_SLOTS * 16 + ns * 16 + ns * 16 + ns * 8;
+    return (size_t)(BS / 64) * (2 * (SQ + KMAX)) * POOL_SLOTS * 16 + ns * 16 + ns * 16 + ns * 8 + 3 * ns * (size_t)n_actions * 8;
 }
 
 // SQ: obstacle-neighbour capacity of the variant (S <= SQ): 4 (the synthetic crowds: one boundary polygon) or 16 (the
 // reference's own worlds: doorway, blocks, tube -- env.py:77-123, ALAN:175-457)
-template <int KMAX, int BS, int SQ>
+// ALAN: the online bandit of ALAN_true.py:569-628 around every step of the launch (ca_alan.h has the same arithmetic as kernels
+// of their own for the lane-per-agent path): softmax over the agent's action weights -> one draw -> preferred velocity = goal
+// direction rotated by the action -> [the ORCA step] -> reward of the action -> sliding-window update of weights and times.
+// Weights and times live in LDS for the whole launch ([action][agent slot] fp64), the four lanes of a quad share the
+// actions (exp64 of the softmax, the window update), the draw is keyed by (seed, global arena, agent, episode, step) as ever.
+template <int KMAX, int BS, int SQ, bool ALAN = false>
 __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
     static_assert(POOL_SLOTS == 16, "a wave holds 16 quads: one line-table slot each");
     static_assert(SQ == 4 || SQ == 16, "obstacle lists of 4 or 16");
@@ -197,6 +204,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
     float* s_vy = s_vx + NS;
     int* s_red = reinterpret_cast<int*>(s_vy + NS);            // [NS][4]; arena la uses row la
     double* s_rew = reinterpret_cast<double*>(s_red + NS * 4);  // [NS]
+    double* s_w = s_rew + NS;                                   // ALAN: [nA][NS] weights | [nA][NS] times | [nA][NS] softmax terms
     int* red = s_red + la * 4;  // per arena: [0] not-done agents, [1] pairs, [2] wall hits, [3] goals
 
     // ---- state of this agent, resident for the whole launch (the four lanes of a quad hold the same values) ----
@@ -227,6 +235,22 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
     float ox = pref.x, oy = pref.y;
     const double KEY_EMPTY = __longlong_as_double(0x7F800000FFFFFFFFll);  // (+inf, -1)
 
+    typedef const __attribute__((address_space(4))) AlanCold AlanK;
+    int nA = 0, last_id = 0;
+    float last_rew = 0.0f;
+    double acc_rew = 0.0;
+    if constexpr (ALAN) {
+        const AlanK& al = *(AlanK*)p.alan;
+        nA = al.nA;
+        for (int k = q; k < nA; k += 4) {
+            s_w[k * NS + slot] = in_arena ? al.w[((size_t)a * nA + k) * N + i] : 0.0;
+            s_w[(nA + k) * NS + slot] = in_arena ? al.t[((size_t)a * nA + k) * N + i] : 0.0;
+        }
+        wave_lds_sync();
+    }
+    double* s_t = s_w + nA * NS;
+    double* s_ps = s_t + nA * NS;
+
     const int T = p.actions ? 1 : (p.T > 0 ? p.T : 1);
     for (int t = 0; t < T; ++t) {
         const bool frozen = (p.flags & 16u) != 0 && in_arena && adone != 0;  // CA_F_FREEZE: the episode of this arena is over
@@ -250,6 +274,37 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
             const double rl_y = pf_x * sn + pf_y * cs;
             pf32 = mk((float)pf_x, (float)pf_y);
             pref = mk((float)rl_x, (float)rl_y);
+        }
+        int act_id = 0;
+        double dgx = 1.0, dgy = 0.0, dlx = 1.0, dly = 0.0;   // goal direction and rotated direction of this step (ALAN:588-595)
+        if constexpr (ALAN) {
+            const AlanK& al = *(AlanK*)p.alan;
+            if (active)
+                for (int k = q; k < nA; k += 4) s_ps[k * NS + slot] = exp64(s_w[k * NS + slot] / al.temp);   // ALAN:580-581
+            wave_lds_sync();
+            if (active) {   // (the four lanes alike from here: every lane of the quad holds the draw and the directions)
+                const double sum = np_sum(nA, [&](int k) { return s_ps[k * NS + slot]; });
+                double acc = 0.0;
+                for (int k = 0; k < nA; ++k) {   // ALAN:582: the normalised terms, in order (the four lanes of the quad store the
+                    const double v = s_ps[k * NS + slot] / sum;   // same value to the same word: one instruction, in lockstep)
+                    s_ps[k * NS + slot] = v;
+                    acc += v;
+                }
+                double ui, u1;
+                if (p.alan_u) ui = p.alan_u[gq];
+                else rng2(c.seed, c.arena_offset + a, i, RNG_ALAN + (epi << 8), (uint32_t)steps, &ui, &u1);
+                act_id = nA - 1;   // np.random.choice (ALAN:585): first action whose normalised cdf exceeds u
+                double run = 0.0;
+                bool found = false;
+                for (int k = 0; k < nA - 1; ++k) {
+                    run += s_ps[k * NS + slot];
+                    if (!found && run / acc > ui) { act_id = k; found = true; }
+                }
+                pref_dir64(pos.x, pos.y, gx, gy, &dgx, &dgy);                       // ALAN:588
+                const double cs = al.act_c[act_id], sn = al.act_s[act_id];         // ALAN:592-595
+                dlx = dgx * cs - dgy * sn; dly = dgx * sn + dgy * cs;
+                pref = mk((float)dlx, (float)dly);                                  // ALAN:598
+            }
         }
         if (q == 0) { s_px[slot] = pos.x; s_py[slot] = pos.y; s_vx[slot] = vel.x; s_vy[slot] = vel.y; }
         __syncthreads();
@@ -528,6 +583,30 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
                 ox = (float)dx; oy = (float)dy;
             }
         }
+        if constexpr (ALAN) {   // reward of the executed action and the sliding-window update (ALAN:603-628)
+            const AlanK& al = *(AlanK*)p.alan;
+            if (active) {
+                {   // env.py:389-400 in fp32, as ca_step reports it
+                    const float scale = (float)al.reward_scale;
+                    const float r_goal = vel.x * (float)dgx + vel.y * (float)dgy;
+                    const float r_polite = vel.x * (float)dlx + vel.y * (float)dly;
+                    last_rew = scale * r_goal + (1.0f - scale) * r_polite;
+                    acc_rew += (double)last_rew;
+                }
+                const double vx = (double)vel.x, vy = (double)vel.y;
+                const double Rw = al.reward_scale * (vx * dgx + vy * dgy) + (1.0 - al.reward_scale) * (vx * dlx + vy * dly);
+                for (int k = q; k < nA; k += 4) {
+                    double tk = s_t[k * NS + slot] + al.dt;
+                    double wk = s_w[k * NS + slot];
+                    if (tk >= al.window) { tk = 0.0; wk = 0.0; }
+                    if (k == act_id) wk = Rw;
+                    s_t[k * NS + slot] = tk; s_w[k * NS + slot] = wk;
+                }
+                pref = mk((float)dlx, (float)dly);   // the agent still holds the velocity it was given at ALAN:598
+                last_id = act_id;
+            }
+            wave_lds_sync();
+        }
         __syncthreads();  // all lanes have read red[] and episode[]
         if (active && i == 0 && q == 0) {
             acc_coll += (unsigned)red[1]; acc_wall += (unsigned)red[2]; acc_goals += (unsigned)red[3];
@@ -547,6 +626,20 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
     }
 
     // ---- write the state back, once ----
+    if constexpr (ALAN) {
+        const AlanK& al = *(AlanK*)p.alan;
+        if (in_arena && touched) {
+            for (int k = q; k < nA; k += 4) {
+                al.w[((size_t)a * nA + k) * N + i] = s_w[k * NS + slot];
+                al.t[((size_t)a * nA + k) * N + i] = s_t[k * NS + slot];
+            }
+            if (q == 0) {
+                al.action[gq] = last_id;
+                al.reward[gq] = last_rew;
+                if (p.flags & 2u) atomicAdd(reinterpret_cast<double*>(&c.arena_stats[(size_t)a * ST_STRIDE + ST_SUMREW]), acc_rew);
+            }
+        }
+    }
     if (in_arena && q == 0 && acc_frozen && i == 0) c.arena_stats[(size_t)a * ST_STRIDE + ST_FROZEN] += acc_frozen;
     if (in_arena && q == 0 && touched) {
         c.orient_x[gq] = ox; c.orient_y[gq] = oy;

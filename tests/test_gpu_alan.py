@@ -244,3 +244,50 @@ def test_alan_draws_differ_between_episodes_of_an_arena():
     H.assert_state_equal(g, e, "two alan episodes")
     assert (runs[0][0] != runs[1][0]).any() and (runs[0] != runs[1]).mean() > 0.3
     g.close()
+
+
+def test_fused_alan_launch_equals_three_launch_form_and_oracle():
+    """Small batches run the bandit INSIDE the four-lanes kernel's launch (one launch per step, one per 256 steps of a
+    rollout; csrc/ca_quad.h); CA_ALAN_FUSED=0 keeps the select -> solve -> update launches.  Both against the oracle, bit
+    for bit (fp64 weights and times included), single steps with caller-supplied uniforms, with the handle's own draws, and
+    as a frozen rollout that ends every arena at its own last step (run_sim, ALAN:106-123)."""
+    import os
+    A, N = 40, 12
+    p = H.scenario_params("circle", N, max_step=90)
+    fused = H.make_gpu(A, N, "circle", p, seed=8)
+    os.environ["CA_ALAN_FUSED"] = "0"
+    try:
+        plain = H.make_gpu(A, N, "circle", p, seed=8)
+        plain.alan_configure(ACTS9)
+    finally:
+        del os.environ["CA_ALAN_FUSED"]
+    e = H.make_oracle(A, N, "circle", p, seed=8)
+    fused.alan_configure(ACTS9); e.alan_configure(ACTS9)
+    assert fused.launch_info()["lanes_per_agent"] == 4
+    rng = np.random.RandomState(6)
+    for s in range(12):                                # the uniforms numpy's choice would consume (ALAN:585)
+        u = rng.uniform(0, 1, (A, N))
+        for env in (fused, plain):
+            env.alan_step(u=u, stats=True)
+        e.alan_step(u=u, flags=o.F_STATS)
+    _assert_alan_equal(fused, e, "fused, given uniforms")
+    _assert_alan_equal(plain, e, "three launches, given uniforms")
+    for s in range(10):
+        for env in (fused, plain):
+            env.alan_step(stats=True, with_obs=(s == 9))
+        e.alan_step(flags=o.F_STATS | (o.F_OBS if s == 9 else 0))
+    _assert_alan_equal(fused, e, "fused, own draws")
+    H._eq(fused.get(_lib.FLD_OBS), e.get(o.FLD_OBS), "fused obs")
+    sc = (np.arange(A) % 31).astype(np.int32) + fused.get(_lib.FLD_STEP_COUNT)     # the arenas end at different steps
+    for env in (fused, plain):
+        env.set(_lib.FLD_STEP_COUNT, sc)
+    e.set(o.FLD_STEP_COUNT, sc)
+    fused.alan_rollout(300, stats=True, freeze=True)     # 256 + 44 steps: two launches
+    plain.alan_rollout(300, stats=True, freeze=True)
+    for s in range(300):
+        e.alan_step(flags=o.F_STATS | o.F_FREEZE)
+    _assert_alan_equal(fused, e, "fused rollout")
+    _assert_alan_equal(plain, e, "three-launch rollout")
+    H.assert_stats_equal(fused, e, "fused rollout")
+    assert fused.get(_lib.FLD_ARENA_DONE).all()
+    fused.close(); plain.close()

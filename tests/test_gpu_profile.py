@@ -52,8 +52,13 @@ def test_small_kernels_are_timed_on_their_own_dispatch():
     ca_alan_step, also with recycled events."""
     A, N = 64, 16
     p = H.scenario_params("crowd", N)
-    env = H.make_gpu(A, N, "crowd", p, seed=2)
-    env.alan_configure([[1.0, 0.0], [0.7, 0.7], [0.7, -0.7], [0.0, 1.0]])
+    import os
+    os.environ["CA_ALAN_FUSED"] = "0"       # the three-launch form of the ALAN step (large batches take it; this small one would
+    try:                                    # run the bandit inside the four-lanes kernel's launch)
+        env = H.make_gpu(A, N, "crowd", p, seed=2)
+        env.alan_configure([[1.0, 0.0], [0.7, 0.7], [0.7, -0.7], [0.0, 1.0]])
+    finally:
+        del os.environ["CA_ALAN_FUSED"]
     for rnd in range(2):                      # the second round reuses the events the first one handed back
         env.profile(1)
         env.profile_read()

@@ -72,7 +72,7 @@ def by_design(name):
     # 448 B of the LDS-table kernel it replaces there); the K = 5 kernel of the reference env's own world has none
     return re.match(r"step_kernel<\d+, \d+, 0, (true|false)(, \d+)*>", name) is not None or \
         re.match(r"step_kernel<10, \d+, 4, true, 1, 16>", name) is not None or \
-        name.startswith("quad_kernel<10, 512, 16>")   # instantiated for the launch switch, never selected (ca_create: 256 lanes at most)
+        name.startswith("quad_kernel<10, 512, 16")   # instantiated for the launch switch, never selected (ca_create: 256 lanes at most)
 
 
 def spilling(rows):
