@@ -48,8 +48,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C5"])
-    ap.add_argument("--mode", default="step", choices=["step", "orca"])
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C5", "A16", "A50", "A100"])
+    ap.add_argument("--mode", default="step", choices=["step", "orca", "alan"],
+                    help="step: full env step (actions in, observation out); orca: ORCA-only rollout; alan: the ALAN online-learning "
+                         "rollout of ALAN_true.py:106-123 (softmax draw -> ORCA step -> bandit update per agent and step, no observation)")
     ap.add_argument("--variant", default="walls", choices=["walls", "free"],
                     help="SURVEY 8d: A = with the boundary polygon (default), B = obstacle-free")
     ap.add_argument("--starts", default="overlap", choices=["overlap", "separated"],
@@ -127,8 +129,27 @@ def cpu_baseline(workload, mode, seconds, variant="walls", starts="overlap"):
     N = w["n_agents"]
     cores = host_cores()
     rng = np.random.RandomState(0)
-    scn = "crowd" if starts == "overlap" else "crowd_separated"
+    scn = w.get("scenario", "crowd") if starts == "overlap" else "crowd_separated"
     flags = o.F_OBS if mode == "step" else 0
+    if mode == "alan":   # the oracle's ALAN step is serial: one core, one batch of arenas, a bounded sample
+        from collision_avoidance_amd import alan as _alan
+        p = scenarios.bench_params(N, w["neighbor_dist"], w["max_neighbors"])
+        p.update(reward_scale=0.6)
+        A1 = max(1, min(64, 2048 // N))
+        env = H.make_oracle(A1, N, scn, p, seed=0)
+        env.alan_configure(_alan.DEFAULT_ACTIONS)
+        for _ in range(3):
+            env.alan_step(flags=o.F_STATS)
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(10):
+                env.alan_step(flags=o.F_STATS)
+            steps += 10
+        dt = time.perf_counter() - t0
+        return {"value": A1 * N * steps / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port", "single_core_value": A1 * N * steps / dt,
+                "sample": "%d arenas x %d agents x %d ALAN online steps on one thread (%.1f s), oracle/ca_oracle.cpp -O2 "
+                          "(its ALAN step has no thread pool)" % (A1, N, steps, dt)}
 
     def run(A, threads, budget):
         p = scenarios.bench_params(N, w["neighbor_dist"], w["max_neighbors"])
@@ -217,13 +238,19 @@ def main():
     p = scenarios.bench_params(N, w["neighbor_dist"], w["max_neighbors"])
     job_rank = rank if args.as_rank is None else args.as_rank
     arena_offset, _ = cad.weak_shard(A, job_rank)  # weak scaling: every GPU owns A arenas of the global range
-    scn = "crowd" if args.starts == "overlap" else "crowd_separated"
+    scn = w.get("scenario", "crowd") if args.starts == "overlap" else "crowd_separated"
+    if args.mode == "alan":
+        p.update(reward_scale=0.6)    # ALAN:47 gamma
     env = VecCollisionAvoidanceEnv(A, N, scenario=scn, params=p, device=local, seed=0,
                                    arena_offset=arena_offset, use_torch=True,
                                    obstacles="scenario" if args.variant == "walls" else [])
     gen = torch.Generator(device="cuda").manual_seed(1234 + job_rank)
     pool = (torch.rand((16, A, N), device="cuda", generator=gen) - 0.5)  # actions in [-0.5, 0.5] rad
     full = args.mode == "step"
+    alan_mode = args.mode == "alan"
+    if alan_mode:
+        from collision_avoidance_amd import alan as _alan
+        env.alan_configure(_alan.DEFAULT_ACTIONS)
 
     chunk = 1 if full else max(1, args.rollout_chunk)
     if args.steps % chunk or args.warmup % chunk:
@@ -234,6 +261,9 @@ def main():
     def one_step(i):  # the production call: one ca_step (neighbours -> ORCA solve -> observation) ...
         if full:
             env._call("ca_step", env.h, pool[i % 16].data_ptr(), _lib.F_STATS | _lib.F_OBS)
+        elif alan_mode:
+            if i % chunk == 0:   # run_sim(mode=1) without the break: `chunk` online steps per call
+                env._call("ca_alan_rollout", env.h, chunk, _lib.F_STATS)
         elif chunk == 1:
             env._call("ca_orca_step", env.h, _lib.F_STATS)
         elif i % chunk == 0:   # ... or one ca_rollout per `chunk` steps of an ORCA-only policy rollout
@@ -273,7 +303,7 @@ def main():
     env.profile(0)
     st = env.stats()
     per_step_calls = None
-    if not full and chunk > 1:   # the same ORCA-only workload through one ca_orca_step call per step, for comparison
+    if not full and not alan_mode and chunk > 1:   # the same ORCA-only workload through one ca_orca_step call per step, for comparison
         torch.cuda.synchronize()
         n2 = max(chunk, min(args.steps, 500))
         t1 = time.perf_counter()
@@ -354,11 +384,12 @@ def main():
             "warmup": args.warmup, "warmup_steps_run": warm_run, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d arenas x %d agents per GPU, random start/goal crowd (ALAN recipe), "
-                                   "neighborDist %.1f, maxNeighbors %d, %s, %s, %s starts" %
+            "config": {"workload": ("%s: %d arenas x %d agents per GPU, " + ("random start/goal crowd (ALAN recipe), " if scn.startswith("crowd") else "ALAN '" + scn + "' scenario, ") +
+                                    "neighborDist %.1f, maxNeighbors %d, %s, %s, %s starts") %
                                    (args.workload, A, N, w["neighbor_dist"], w["max_neighbors"],
                                     "full env step (action -> ORCA -> reward/done -> laser obs)" if full
-                                    else "ORCA-only step (no observation)",
+                                    else ("ALAN online step (softmax draw -> ORCA -> bandit update; no observation)" if alan_mode
+                                          else "ORCA-only step (no observation)"),
                                     "boundary walls" if args.variant == "walls" else "obstacle-free", args.starts),
                        "mode": args.mode, "variant": args.variant, "starts": args.starts,
                        "rollout_chunk": chunk, "steps_per_launch": steps_per_launch, "lanes_per_agent": lanes_per_agent,

@@ -194,4 +194,9 @@ BENCH_CONFIGS = {
     "C2": dict(n_arenas=1024, n_agents=16, neighbor_dist=1.5, max_neighbors=5),
     "C3": dict(n_arenas=4096, n_agents=64, neighbor_dist=5.0, max_neighbors=10),
     "C5": dict(n_arenas=256, n_agents=512, neighbor_dist=5.0, max_neighbors=10),
+    # ALAN online learning (bench.py --mode alan; ALAN_true.py:106-123, 569-628): the paper's simulator constants
+    # (neighborDist 5, maxNeighbors 10) on three batch shapes
+    "A16": dict(n_arenas=1024, n_agents=16, neighbor_dist=5.0, max_neighbors=10),
+    "A50": dict(n_arenas=1024, n_agents=50, neighbor_dist=5.0, max_neighbors=10),
+    "A100": dict(n_arenas=1024, n_agents=100, neighbor_dist=5.0, max_neighbors=10, scenario="circle"),
 }
