@@ -890,15 +890,20 @@ int ca_get_obstacles_arena(ca_env* e, int32_t arena, float* verts_xy, int32_t* n
     return get_table(e, arena, verts_xy, next, convex, cap, n_out);
 }
 
-int ca_init_scenario(ca_env* e, int32_t scenario) {
-    if (!e) return CA_EINVAL;
-    if (scenario < 0 || scenario > CA_SCN_CROWD_SEPARATED)
-        return fail(e, CA_EINVAL, "ca_init_scenario: unknown scenario %d", scenario);
+}  // extern "C" (the scenario generators below are plain C++)
+
+// The scenario generators (env.py:86-97, ALAN:175-457) on the host, for arenas [0, An): An = n_arenas for the one scenario
+// whose draws are sequential per arena (rejection-sampled starts), An = 1 for the per-agent TABLE of the others -- their
+// layout either does not depend on the arena at all (circle, incoming, blocks, deadlock: libm's cos / sin / sqrt stay on the
+// host) or only through counter-based draws, which init_scenario_kernel makes on the device.
+static void host_scenario(const ca_env* e, int scenario, int An, std::vector<float>& px, std::vector<float>& py, std::vector<float>& vx,
+                          std::vector<float>& vy, std::vector<float>& fx, std::vector<float>& fy, std::vector<double>& gx,
+                          std::vector<double>& gy, std::vector<double>& g2x, std::vector<double>& g2y) {
     const ca_config& c = e->cfg;
-    const int A = c.n_arenas, N = c.n_agents;
-    const size_t an = AN(e);
-    std::vector<float> px(an), py(an), vx(an), vy(an), fx(an), fy(an);
-    std::vector<double> gx(an), gy(an), g2x(an), g2y(an);
+    const int A = An, N = c.n_agents;
+    const size_t an = (size_t)An * N;
+    px.assign(an, 0.0f); py.assign(an, 0.0f); vx.assign(an, 0.0f); vy.assign(an, 0.0f); fx.assign(an, 0.0f); fy.assign(an, 0.0f);
+    gx.assign(an, 0.0); gy.assign(an, 0.0); g2x.assign(an, 0.0); g2y.assign(an, 0.0);
     const double r = (double)c.radius;
     for (int a = 0; a < A; ++a) {
         const int64_t g = c.arena_offset + a;
@@ -985,14 +990,101 @@ int ca_init_scenario(ca_env* e, int32_t scenario) {
             fx[q] = (float)dx; fy[q] = (float)dy;
         }
     }
+}
+
+struct InitArgs {
+    float *pos_x, *pos_y, *vel_x, *vel_y, *pref_x, *pref_y;
+    double *goal_x, *goal_y, *goal2_x, *goal2_y;
+    const float *tpx, *tpy;                      // [N] table: start of agent i (arena-independent scenarios)
+    const double *tgx, *tgy, *tg2x, *tg2y;       // [N] table: targets of agent i
+    double x0, x1, y0, y1;                       // box of the drawn starts (pos_rng)
+    double ge;                                   // drawn goals: uniform in (0, ge)^2 (goal_rng)
+    uint64_t seed;
+    int64_t arena_offset;
+    int A, N, pos_rng, goal_rng;
+};
+// every agent of every arena: heading drawn (env.py:89-90 / ALAN:276-277), start and targets drawn or from the table,
+// preferred velocity towards the target (env.py:97) -- the same counter-based streams and the same fp64 operations as the host
+// path (ca_math.h), so the state is the host path's bit for bit
+__global__ void init_scenario_kernel(const InitArgs p) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (size_t)p.A * p.N) return;
+    const int a = (int)(q / p.N), i = (int)(q - (size_t)a * p.N);
+    const int64_t g = p.arena_offset + a;
+    double u0, u1, s, cs;
+    rng2(p.seed, g, i, RNG_HEADING, 0, &u0, &u1);
+    sincos64(uniform64(0.0, 2.0 * M_PI, u0), &s, &cs);
+    p.vel_x[q] = (float)cs; p.vel_y[q] = (float)s;
+    float px = p.tpx[i], py = p.tpy[i];
+    double gx = p.tgx[i], gy = p.tgy[i], g2x = p.tg2x[i], g2y = p.tg2y[i];
+    if (p.pos_rng) {
+        rng2(p.seed, g, i, RNG_POS, 0, &u0, &u1);
+        px = (float)uniform64(p.x0, p.x1, u0); py = (float)uniform64(p.y0, p.y1, u1);
+    }
+    if (p.goal_rng) {
+        rng2(p.seed, g, i, RNG_GOAL, 0, &u0, &u1);
+        gx = uniform64(0.0, p.ge, u0); gy = uniform64(0.0, p.ge, u1);
+        g2x = gx; g2y = gy;
+    }
+    double dx, dy;
+    pref_dir64(px, py, gx, gy, &dx, &dy);
+    p.pos_x[q] = px; p.pos_y[q] = py; p.pref_x[q] = (float)dx; p.pref_y[q] = (float)dy;
+    p.goal_x[q] = gx; p.goal_y[q] = gy; p.goal2_x[q] = g2x; p.goal2_y[q] = g2y;
+}
+
+extern "C" {
+
+int ca_init_scenario(ca_env* e, int32_t scenario) {
+    if (!e) return CA_EINVAL;
+    if (scenario < 0 || scenario > CA_SCN_CROWD_SEPARATED)
+        return fail(e, CA_EINVAL, "ca_init_scenario: unknown scenario %d", scenario);
+    const ca_config& c = e->cfg;
+    const int A = c.n_arenas, N = c.n_agents;
+    const size_t an = AN(e);
+    const bool on_host = scenario == CA_SCN_CROWD_SEPARATED;   // sequential draws per arena (each start depends on the ones before)
+    std::vector<float> px, py, vx, vy, fx, fy;
+    std::vector<double> gx, gy, g2x, g2y;
+    host_scenario(e, scenario, on_host ? A : 1, px, py, vx, vy, fx, fy, gx, gy, g2x, g2y);
     HIPCHK(e, hipSetDevice(e->device));
-    struct { float* d; std::vector<float>* h; } up[] = {{e->pos_x, &px}, {e->pos_y, &py}, {e->vel_x, &vx},
-        {e->vel_y, &vy}, {e->pref_x, &fx}, {e->pref_y, &fy}};
-    struct { double* d; std::vector<double>* h; } upd[] = {{e->goal_x, &gx}, {e->goal_y, &gy},
-        {e->goal2_x, &g2x}, {e->goal2_y, &g2y}};
     hipStream_t st = e->stream;  // everything below is ordered on the handle's stream (see dalloc)
-    for (auto& u : up) HIPCHK(e, hipMemcpyAsync(u.d, u.h->data(), an * 4, hipMemcpyHostToDevice, st));
-    for (auto& u : upd) HIPCHK(e, hipMemcpyAsync(u.d, u.h->data(), an * 8, hipMemcpyHostToDevice, st));
+    if (on_host) {
+        struct { float* d; std::vector<float>* h; } up[] = {{e->pos_x, &px}, {e->pos_y, &py}, {e->vel_x, &vx},
+            {e->vel_y, &vy}, {e->pref_x, &fx}, {e->pref_y, &fy}};
+        struct { double* d; std::vector<double>* h; } upd[] = {{e->goal_x, &gx}, {e->goal_y, &gy},
+            {e->goal2_x, &g2x}, {e->goal2_y, &g2y}};
+        for (auto& u : up) HIPCHK(e, hipMemcpyAsync(u.d, u.h->data(), an * 4, hipMemcpyHostToDevice, st));
+        for (auto& u : upd) HIPCHK(e, hipMemcpyAsync(u.d, u.h->data(), an * 8, hipMemcpyHostToDevice, st));
+    } else {   // the per-agent table (N entries) goes up, the kernel fills A x N agents
+        char* tab = nullptr;
+        const size_t nb = (size_t)N * (2 * 4 + 4 * 8);
+        HIPCHK(e, hipMalloc((void**)&tab, nb));
+        std::vector<char> h(nb);
+        memcpy(h.data(), px.data(), (size_t)N * 4); memcpy(h.data() + (size_t)N * 4, py.data(), (size_t)N * 4);
+        memcpy(h.data() + (size_t)N * 8, gx.data(), (size_t)N * 8); memcpy(h.data() + (size_t)N * 16, gy.data(), (size_t)N * 8);
+        memcpy(h.data() + (size_t)N * 24, g2x.data(), (size_t)N * 8); memcpy(h.data() + (size_t)N * 32, g2y.data(), (size_t)N * 8);
+        hipError_t r = hipMemcpyAsync(tab, h.data(), nb, hipMemcpyHostToDevice, st);
+        if (r == hipSuccess) {
+            InitArgs ia;
+            ia.pos_x = e->pos_x; ia.pos_y = e->pos_y; ia.vel_x = e->vel_x; ia.vel_y = e->vel_y; ia.pref_x = e->pref_x; ia.pref_y = e->pref_y;
+            ia.goal_x = e->goal_x; ia.goal_y = e->goal_y; ia.goal2_x = e->goal2_x; ia.goal2_y = e->goal2_y;
+            ia.tpx = (const float*)tab; ia.tpy = (const float*)(tab + (size_t)N * 4);
+            ia.tgx = (const double*)(tab + (size_t)N * 8); ia.tgy = (const double*)(tab + (size_t)N * 16);
+            ia.tg2x = (const double*)(tab + (size_t)N * 24); ia.tg2y = (const double*)(tab + (size_t)N * 32);
+            const double r2 = (double)c.radius;
+            ia.pos_rng = (scenario == CA_SCN_CROWD || scenario == CA_SCN_CONGESTED || scenario == CA_SCN_DOORWAY) ? 1 : 0;
+            ia.goal_rng = scenario == CA_SCN_CROWD ? 1 : 0;
+            ia.x0 = 0.0; ia.x1 = 0.0; ia.y0 = 0.0; ia.y1 = 0.0; ia.ge = 0.0;
+            if (scenario == CA_SCN_CROWD) { const double E = std::sqrt(2.0 * r2 * N) * 2.0; ia.x1 = E; ia.y1 = E; ia.ge = E; }             // ALAN:270-283
+            else if (scenario == CA_SCN_CONGESTED) { const double E = std::sqrt(2 * r2 * N) * 3; ia.x0 = E * 0.2; ia.x1 = E; ia.y1 = E; }  // ALAN:177-186
+            else if (scenario == CA_SCN_DOORWAY) { const double E = 10.0; ia.x0 = E * 0.5; ia.x1 = E; ia.y1 = E; }                        // env.py:86-95
+            ia.seed = c.seed; ia.arena_offset = c.arena_offset; ia.A = A; ia.N = N;
+            hipLaunchKernelGGL(init_scenario_kernel, dim3((unsigned)((an + 255) / 256)), dim3(256), 0, st, ia);
+            r = hipGetLastError();
+        }
+        if (r == hipSuccess) r = hipStreamSynchronize(st);   // the table and the host staging go away
+        hipFree(tab);
+        if (r != hipSuccess) return fail(e, CA_EHIP, "ca_init_scenario: %s", hipGetErrorString(r));
+    }
     HIPCHK(e, hipMemsetAsync(e->agent_done, 0, an * 4, st));
     HIPCHK(e, hipMemsetAsync(e->arrive_step, 0xff, an * 4, st));
     HIPCHK(e, hipMemsetAsync(e->regoal_count, 0, an * 4, st));

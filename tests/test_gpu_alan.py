@@ -4,6 +4,8 @@ recorded runs of the reference (tests/golden/alan_online.npz), and the Collision
 import numpy as np
 import pytest
 
+from tools import alan_actions
+
 from collision_avoidance_amd import _lib, alan, scenarios
 from oracle import oracle as o
 from tests import helpers as H
@@ -180,7 +182,7 @@ def test_reset_draws_a_new_world_and_batched_evaluation():
     assert not np.array_equal(p0, p1) and r1 != r2 and sim.vec.n_actions == 2
     # the three rounds of the trainer's evaluation == arenas 0..2 of one batched handle
     acts = [(1, 0), (0.6, -0.8), (-0.5, 0.86)]
-    mean_tt, ok = alan.evaluate_actions(acts, numAgents=8, scenario="crowd", num=3, seed=7)
+    mean_tt, ok = alan_actions.evaluate_actions(acts, numAgents=8, scenario="crowd", num=3, seed=7)
     seq = alan.Collision_Avoidance_Sim(numAgents=8, scenario="crowd", online_actions=acts, seed=7)
     tts = []
     for r in range(3):

@@ -7,6 +7,8 @@ import re
 
 import pytest
 
+from tools import alan_actions
+
 from collision_avoidance_amd import _lib, scenarios
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -102,14 +104,14 @@ def test_action_set_files(tmp_path):
     from collision_avoidance_amd import alan
     f = tmp_path / "crowd_actions.act"
     f.write_text("[(1, 0), (0.06130798855686512, -0.9981188959934139), (-0.6767380373137093, 0.7362238985884584)]")
-    acts = alan.load_actions(str(f))
+    acts = alan_actions.load_actions(str(f))
     assert acts == [(1.0, 0.0), (0.06130798855686512, -0.9981188959934139), (-0.6767380373137093, 0.7362238985884584)]
     g = tmp_path / "out.act"
-    alan.save_actions(str(g), acts)
-    assert alan.load_actions(str(g)) == acts
+    alan_actions.save_actions(str(g), acts)
+    assert alan_actions.load_actions(str(g)) == acts
     (tmp_path / "bad.act").write_text("[]")
     with pytest.raises(ValueError):
-        alan.load_actions(str(tmp_path / "bad.act"))
+        alan_actions.load_actions(str(tmp_path / "bad.act"))
 
 
 def test_no_hot_kernel_uses_scratch_memory():
@@ -125,6 +127,13 @@ def test_no_hot_kernel_uses_scratch_memory():
         pytest.skip("no hipcc")
     kr.ensure_asm()
     rows = kr.parse()
-    assert any("step_kernel<10, 64, 4, true" in r["name"] for r in rows) and any("quad_kernel<5, 64, 4>" in r["name"] for r in rows) and any("quad_kernel<10, 256, 16>" in r["name"] for r in rows)
+    names = [r["name"] for r in rows]
+    for want in ("step_kernel<10, 64, 4, true, 1, 4>", "quad_kernel<5, 64, 4, false>", "quad_kernel<10, 256, 16, false>",
+                 "quad_kernel<5, 64, 4, true>", "pair_kernel<10, 512>", "step_kernel<5, 64, 4, true, 1, 16>"):
+        assert any(n.startswith(want) for n in names), want
     bad = kr.spilling(rows)
     assert not bad, [(r["name"], r["scratch"], r["vgpr_spill"]) for r in bad]
+    # the kernel the reference env's OWN world selects (doorway, K = 5, obstacle lists of up to 16: env.py:26-44, 117-122)
+    # is not among the exemptions: no scratch at all
+    own = [r for r in rows if r["name"].startswith("step_kernel<5, 64, 4, true, 1, 16>")]
+    assert own and own[0]["scratch"] == 0 and own[0]["vgpr_spill"] == 0, own

@@ -10,6 +10,8 @@ import os
 import numpy as np
 import pytest
 
+from tools import alan_actions
+
 from collision_avoidance_amd import scenarios
 from oracle import oracle as o
 from tests import helpers as H
@@ -198,7 +200,7 @@ def test_per_arena_obstacle_trainer_evaluation_over_random_block_worlds():
     own four random blocks, and equal the same rounds run one after the other."""
     from collision_avoidance_amd import alan
     acts = [(1, 0), (0.6, -0.8), (-0.5, 0.86)]
-    mean_tt, ok = alan.evaluate_actions(acts, numAgents=8, scenario="blocks", num=3, seed=11)
+    mean_tt, ok = alan_actions.evaluate_actions(acts, numAgents=8, scenario="blocks", num=3, seed=11)
     seq = alan.Collision_Avoidance_Sim(numAgents=8, scenario="blocks", online_actions=acts, seed=11)
     tts, tabs = [], []
     for r in range(3):
@@ -274,4 +276,24 @@ def test_small_world_with_many_edges_in_range_on_the_register_line_kernel(K, N, 
     H.assert_stats_equal(g, e, "round room")
     assert many > (0.3 if N <= 12 else 0.05) * 60 * A * N, many          # the stage was really exercised
     assert g.stats()["obst_overflow"] == 0
+    g.close()
+
+
+@pytest.mark.gpu
+def test_large_arena_with_sixteen_obstacle_neighbours_is_accepted():
+    """300 agents per arena with the default obstacle-list capacity of a 14-edge world: the LDS line table would need more
+    than the 160 KB of a CU (round 3 refused the configuration with CA_ERANGE); the register-line kernel with the
+    many-obstacles stage takes it."""
+    N, A = 300, 2
+    p = H.scenario_params("crowd", N, max_neighbors=5, neighbor_dist=2.0)
+    walls = scenarios.obstacles("doorway", 10)
+    p.update(spawn_x0=3.0, spawn_x1=9.5, spawn_y0=0.5, spawn_y1=9.5, goal_x0=-10.0, goal_x1=1.0, goal_y0=1.0, goal_y1=9.0)
+    g = H.make_gpu(A, N, "crowd", p, seed=3, polys=walls)
+    e = H.make_oracle(A, N, "crowd", p, seed=3, polys=walls)
+    assert g.S == 14 and g.launch_info()["lanes_per_agent"] == 1
+    g.reset(); e.reset()
+    for s in range(40):
+        g.orca_step(stats=True, with_obs=(s == 39)); e.orca_step(flags=o.F_STATS | (o.F_OBS if s == 39 else 0))
+    H.assert_state_equal(g, e, "300 agents behind the doorway", obs=True)
+    H.assert_stats_equal(g, e, "300 agents behind the doorway")
     g.close()
