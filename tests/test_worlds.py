@@ -290,7 +290,7 @@ def test_large_arena_with_sixteen_obstacle_neighbours_is_accepted():
     p.update(spawn_x0=3.0, spawn_x1=9.5, spawn_y0=0.5, spawn_y1=9.5, goal_x0=-10.0, goal_x1=1.0, goal_y0=1.0, goal_y1=9.0)
     g = H.make_gpu(A, N, "crowd", p, seed=3, polys=walls)
     e = H.make_oracle(A, N, "crowd", p, seed=3, polys=walls)
-    assert g.S == 14 and g.launch_info()["lanes_per_agent"] == 1
+    assert g.S == 12 and g.launch_info()["lanes_per_agent"] == 1      # (12 edges before processObstacles cuts two of them)
     g.reset(); e.reset()
     for s in range(40):
         g.orca_step(stats=True, with_obs=(s == 39)); e.orca_step(flags=o.F_STATS | (o.F_OBS if s == 39 else 0))
