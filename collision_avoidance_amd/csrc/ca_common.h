@@ -91,6 +91,8 @@ struct StepArgs {
     // linv != 0: arenas within one wave whose N is not a power of two -- N lanes each, back to back (the reference env's own
     // 10-agent arenas: six per wave instead of four); linv = ceil(2^16 / N), so that (lane * linv) >> 16 = lane / N
     int LS, apb, linv;
+    int nb_hint;   // 1: the agent-neighbour lists in memory are those a solve kernel left (K distinct agents each): the pair
+                   // kernel bounds its scan with them (ca_pair.h); 0 after the caller wrote the lists through ca_set
     int T;       // quad kernel, ORCA-only mode: steps advanced by this launch (ca_quad.h); 1 otherwise
     uint32_t flags;
     float time_step, neighbor_dist, time_horizon, time_horizon_obst, radius, max_speed;

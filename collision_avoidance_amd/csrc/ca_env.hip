@@ -63,6 +63,7 @@ struct ca_env {
     int* d_order = nullptr;          // [grid] block order of the solve kernel (null: identity)
     int P = 1, logP = 0, BS = 64, grid = 1, K = 0, S = 1;
     bool obs_dense_on = false;
+    bool lists_trusted = true;   // the neighbour lists in memory were written by the kernels (not by the caller through ca_set)
     int LS = 1, apb = 1, linv = 0;   // lanes per arena, arenas per workgroup, ceil(2^16 / LS) or 0 (ca_common.h StepArgs)
     int BSn = 64, grid_n = 1;  // the neighbour kernel's own workgroup size
     bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
@@ -228,7 +229,7 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.reset_px = nullptr; a.reset_py = nullptr; a.reset_mask = nullptr; a.dbg = e->dbg;
     a.n_obst = e->h_tab_off.empty() ? (int)e->h_obst.size() : 0; a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
     a.K = e->K; a.S = e->S; a.flags = flags; a.a0 = 0; a.a1 = c.n_arenas; a.T = 1;
-    a.LS = e->LS; a.apb = e->apb; a.linv = e->linv;
+    a.LS = e->LS; a.apb = e->apb; a.linv = e->linv; a.nb_hint = e->lists_trusted ? 1 : 0;
     a.time_step = c.time_step; a.neighbor_dist = c.neighbor_dist; a.time_horizon = c.time_horizon;
     a.time_horizon_obst = c.time_horizon_obst; a.radius = c.radius; a.max_speed = c.max_speed;
 }
@@ -316,7 +317,13 @@ static hipError_t launch_quad(ca_env* e, const StepArgs& a) {
     if (ps.t0) return hipExtLaunchKernel(quad_fn(e, alan), dim3(e->grid_q), dim3(e->BSq), params, lds, e->stream, ps.t0, ps.t1, 0);
     return hipLaunchKernel(quad_fn(e, alan), dim3(e->grid_q), dim3(e->BSq), params, lds, e->stream);
 }
+static hipError_t launch_step_any(ca_env* e, const StepArgs& a);
 static hipError_t launch_step(ca_env* e, const StepArgs& a) {
+    const hipError_t r = launch_step_any(e, a);
+    if (!(a.flags & CA_F_FREEZE)) e->lists_trusted = true;   // every arena's lists are this launch's now (frozen arenas keep theirs)
+    return r;
+}
+static hipError_t launch_step_any(ca_env* e, const StepArgs& a) {
     if (e->quad || (a.T > 1 && e->quad_roll) || a.alan != nullptr) return launch_quad(e, a);
     if (e->ST > 0) return e->KT == 5 ? launch_step_k<5, 4>(e, a) : launch_step_k<10, 4>(e, a);
     if (e->K <= 5) return launch_step_k<5, 0>(e, a);
@@ -1137,6 +1144,7 @@ int ca_set(ca_env* e, int32_t field, const void* src, size_t bytes, int32_t src_
     if (bytes != fi.bytes) return fail(e, CA_ESIZE, "ca_set: field %d holds %zu bytes, got %zu", field, fi.bytes, bytes);
     HIPCHK(e, hipSetDevice(e->device));
     if (packed_field(field)) {
+        e->lists_trusted = false;   // (until the next solve launch has rewritten them)
         const size_t n = bytes / 4;
         const int rc = cvt_reserve(e, n);
         if (rc) return rc;

@@ -189,8 +189,8 @@ __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
 
     CA_PSTAMP(0);
     // ---- stage the arena: slot sl loads agent sl (coalesced); preferred velocity of this step (env.py:371-383) ----
-    int cx, cy, Gx, Gy, RC;
-    float cs;
+    int Gx, Gy;
+    float gx0, gy0, gics;   // the grid: origin and 1 / cell size
     {
         V2 pos0 = mk(0.0f, 0.0f), vel0 = mk(0.0f, 0.0f), pref0 = mk(0.0f, 0.0f);
         V2 pf0 = mk(1.0f, 0.0f);
@@ -236,9 +236,10 @@ __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
         __syncthreads();
         const float x0 = unord(s_box[0]), y0 = unord(s_box[1]);
         const float ex = unord(s_box[2]) - x0, ey = unord(s_box[3]) - y0;
-        cs = fmaxf(0.5f * p.neighbor_dist, fmaxf(ex, ey) * (1.0f / (GMAX - 0.5f)));
-        RC = (cs >= p.neighbor_dist) ? 1 : 2;
+        // cells a quarter of the neighbour range wide, or wider when 32 x 32 of them would not cover the arena
+        const float cs = fmaxf(0.25f * p.neighbor_dist, fmaxf(ex, ey) * (1.0f / (GMAX - 0.5f)));
         const float ics = 1.0f / cs;
+        gx0 = x0; gy0 = y0; gics = ics;
         Gx = min(GMAX, (int)(ex * ics) + 1); Gy = min(GMAX, (int)(ey * ics) + 1);
         auto cell_of = [&](V2 q2, int& ccx, int& ccy) {
             ccx = min(Gx - 1, max(0, (int)((q2.x - x0) * ics))); ccy = min(Gy - 1, max(0, (int)((q2.y - y0) * ics)));
@@ -269,8 +270,7 @@ __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
         __syncthreads();
         // ---- FROM HERE ON the pair of slot sl works for the agent at position sl of the SORTED list: a wave's 32 agents are
         // neighbours in space, so they walk the same cell rows (the candidate reads are LDS broadcasts, the loops of a wave
-        // have one trip count), agree on whether the outer ring of cells is needed, and need LP3 together or not at all ----
-        cell_of(in_arena ? mk(s_sxy[sl].x, s_sxy[sl].y) : pos0, cx, cy);
+        // have one trip count), need blocks of cells of the same size, and need LP3 together or not at all ----
     }
     const int i = in_arena ? (int)s_sorted[sl] : sl;
     const int q = active ? a * N + i : 0;
@@ -318,20 +318,44 @@ __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
         CA_PSTAMP(3);
         if (K > 0) {
             const float rangeSq0 = sqr(p.neighbor_dist);
-            // INNER BLOCK FIRST.  With cells half a neighbour range wide (RC = 2) the 3 x 3 block around the agent's cell
-            // holds every agent within one cell width of it: once that block has yielded K candidates closer than 0.999 cs
-            // (the 0.1 % covers the rounding of the cell assignment: ~1e-5 of a cell), nothing in the outer ring of 16 cells
-            // can enter the list, and the ring -- two thirds of the candidates of a settled, contracted crowd, where an
-            // agent has ~90 others within its neighbour range and ~180 in the 5 x 5 block -- is skipped.  The count is taken
-            // over both lanes of the pair (each sees every other candidate).
-            const float nearSq = sqr(0.999f * cs);
-            int n_near = 0;
-            auto run = [&](int row, int c0, int c1) __attribute__((always_inline)) {   // cells c0 .. c1 of a row: one run of the sorted list
-                int lo = 0, hi = 0;
-                if (active && row >= 0 && row < Gy && c1 >= 0 && c0 < Gx) {
-                    lo = s_cstart[row * Gx + max(c0, 0)];
-                    hi = s_cstart[row * Gx + min(c1, Gx - 1) + 1];
-                }
+            // HOW FAR TO LOOK.  The list this agent had after the last step names K other agents; wherever they are now, the
+            // farthest of them bounds the distance of the K-th nearest agent now -- so the scan covers the cells that the disc
+            // of that radius touches, not the whole neighbour range (a settled, contracted crowd: ~90 agents within the
+            // neighbour range of 5, the tenth-nearest at 2.6 on average).  Any K distinct agents give a valid bound: nothing
+            // depends on the list being fresh (after a reset it merely is a looser bound); a list the caller wrote through
+            // ca_set is not trusted (p.nb_hint = 0), and a list shorter than K means the whole range.
+            float b2 = rangeSq0;
+            if (p.nb_hint && active && (int)(p.counts[q] & 0xFFu) == K) {
+                float far2 = 0.0f;
+                bool bad = false;
+                int jn[KH];
+                static_for<KH>([&](auto mc) __attribute__((always_inline)) {
+                    constexpr int m = decltype(mc)::value;
+                    jn[m] = (2 * m + h < K) ? ld_idx_t<CA_NBW16(BS)>(p.nb_idx, ((size_t)a * K + (2 * m + h)) * N + i) : -1;
+                });
+                static_for<KH>([&](auto mc) __attribute__((always_inline)) {
+                    constexpr int m = decltype(mc)::value;
+                    if (2 * m + h < K) {
+                        const int j = jn[m];
+                        const bool okj = j >= 0 && j < N && j != i;
+                        const float d2 = absSq(pos - mk(s_px[okj ? j : i], s_py[okj ? j : i]));
+                        far2 = d2 > far2 ? d2 : far2;
+                        bad = bad || !okj;
+                    }
+                });
+                const float of = quad_xor<0xB1>(far2);
+                far2 = of > far2 ? of : far2;
+                bad = bad || quad_xor<0xB1>(bad ? 1 : 0) != 0;
+                if (!bad && far2 < rangeSq0) b2 = far2;
+            }
+            // the cells the closed disc of radius sqrt(b2) touches (+ 1e-4 relative and absolute: the cell index is a
+            // monotone function of the coordinate, so a candidate within that distance lies in a cell between the cells of
+            // the disc's extreme points)
+            const float Bm = sqrtf(b2) * 1.0001f + 1e-4f;
+            const int cxlo = max(0, (int)((pos.x - Bm - gx0) * gics)), cxhi = min(Gx - 1, (int)((pos.x + Bm - gx0) * gics));
+            const int cylo = max(0, (int)((pos.y - Bm - gy0) * gics)), cyhi = min(Gy - 1, (int)((pos.y + Bm - gy0) * gics));
+            for (int row = cylo; row <= (active ? cyhi : cylo - 1); ++row) {   // one run of the sorted list per cell row
+                const int lo = s_cstart[row * Gx + cxlo], hi = s_cstart[row * Gx + cxhi + 1];
                 int t = lo + h;
                 int jn = 0;
                 float2 on = make_float2(0.0f, 0.0f);
@@ -343,20 +367,8 @@ __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
                     if (t < hi) { jn = s_sorted[t]; on = s_sxy[t]; }  // the next candidate is in flight during this one
                     const float dsq = absSq(pos - o);
                     const bool ok = j != i && dsq < rangeSq0;
-                    n_near += (ok && dsq < nearSq) ? 1 : 0;
                     sorted_insert_n<KMAX>(nkey, ok ? make_key(dsq, j) : KEY_EMPTY);
                 }
-            };
-            if (RC == 2) {
-                for (int ry = -1; ry <= 1; ++ry) run(cy + ry, cx - 1, cx + 1);
-                const bool more = active && pair_sum(n_near) < K;          // (the same verdict in both lanes of the pair)
-                if (more) {
-                    run(cy - 2, cx - 2, cx + 2);
-                    run(cy + 2, cx - 2, cx + 2);
-                    for (int ry = -1; ry <= 1; ++ry) { run(cy + ry, cx - 2, cx - 2); run(cy + ry, cx + 2, cx + 2); }
-                }
-            } else {
-                for (int ry = -1; ry <= 1; ++ry) run(cy + ry, cx - 1, cx + 1);
             }
             merge_with_partner<M, 0xB1>(nkey);   // both lanes: the KMAX smallest keys of the two lists, ascending
         }
@@ -442,8 +454,9 @@ __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
     CA_PSTAMP(7);
     // ---- LP3 for the agents whose LP2 was infeasible: the pair copies its lines into a slot of the wave's LDS pool and the
     // whole wave solves the slots, four lanes each (ca_lp.h lp3_coop).  (Dealing the arena's infeasible agents over the
-    // pools of ALL its waves -- they cluster in the waves of the dense core -- was built and measured: the same kernel time,
-    // a round of lp3_coop is as long as its slowest slot either way; profiles/r04_b_c5_pair_kernel.txt.) ----
+    // pools of ALL its waves -- they cluster in the waves of the dense core -- was built and measured twice, before and
+    // after the scan was shortened: the same kernel time, a round of lp3_coop is as long as its slowest slot whoever runs
+    // it; profiles/r04_b_c5_pair_kernel.txt.) ----
     {
         float4* pool = s_lines + (size_t)(tid >> 6) * (2 * ML) * POOL_SLOTS;
         float4* hdr = pool + (size_t)(2 * ML - 1) * POOL_SLOTS;
