@@ -84,3 +84,31 @@ def test_pair_done_modes_and_freeze():
     assert g.get(_lib.FLD_ARENA_DONE).tolist() == [0, 1] and g.stats()["agent_steps"] == N * (30 + 15)
     np.testing.assert_array_equal(g.get(_lib.FLD_ARRIVE_STEP), e.get(o.FLD_ARRIVE_STEP))
     g.close()
+
+
+def test_scan_bound_does_not_trust_lists_written_by_the_caller():
+    """The pair kernel bounds its neighbour scan with the agent's list of the previous step (any K distinct agents bound the
+    K-th nearest).  A list the CALLER wrote through ca_set may name anything -- here the same agent ten times --: the next
+    step must ignore it as a bound and still produce the exact lists; after a reset (stale but valid lists) the bound is
+    merely looser."""
+    A, N, K = 2, 400, 10
+    p = H.scenario_params("crowd", N)
+    g = H.make_gpu(A, N, "crowd", p, seed=12)
+    e = H.make_oracle(A, N, "crowd", p, seed=12)
+    assert g.launch_info()["lanes_per_agent"] == 2
+    for s in range(5):
+        g.orca_step(stats=True); e.orca_step(flags=o.F_STATS)
+    H.assert_state_equal(g, e, "before")
+    junk = np.zeros((A, K, N), np.int32)
+    junk[:, :, :] = (np.arange(N)[None, None, :] + 1) % N          # every entry of agent i names agent i + 1
+    cnt = np.full((A, N), K, np.int32)
+    g.set(_lib.FLD_NB_IDX, junk); g.set(_lib.FLD_NB_COUNT, cnt)
+    e.set(o.FLD_NB_IDX, np.ascontiguousarray(junk.transpose(0, 2, 1)))     # (the oracle keeps [A, N, K]; the count follows)
+    g.orca_step(stats=True); e.orca_step(flags=o.F_STATS)
+    H.assert_state_equal(g, e, "after a step from junk lists")
+    g.reset(with_obs=False); e.reset(flags=0)                       # new positions, the lists stay (env.py:461-488)
+    for s in range(3):
+        g.orca_step(stats=True); e.orca_step(flags=o.F_STATS)
+    H.assert_state_equal(g, e, "after a reset")
+    H.assert_stats_equal(g, e, "junk lists")
+    g.close()
