@@ -266,8 +266,8 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
             scanned = true;
         }
     }
-    if (K > 0 && !scanned && N <= 64) {
-        // Arenas of at most 64 agents: 32-bit composite keys = (fixed-point distance << logP) | candidate index and
+    if (K > 0 && !scanned && N <= 256) {
+        // Arenas of at most 256 agents (brute-force scan; 8-bit agent ids): 32-bit composite keys = (fixed-point distance << logP) | candidate index and
         // one v_med3_u32 per list slot and candidate -- new[k] = med3(old[k-1], old[k], x) IS the sorted insert,
         // at half the instructions of the 64-bit network (in so small an arena some lane accepts nearly every
         // candidate, so the shrinking range of the contract never lets a wave skip the network anyway).  The
@@ -277,7 +277,8 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
         // lane whose K+1 smallest composites have pairwise different images provably holds the exact list:
         // strictly increasing images order the first K exactly and put every other candidate behind them.  A
         // wave in which some lane fails that test (exact fp32 ties, e.g. the symmetric circle world; ~2e-3 of the
-        // waves of a random crowd) falls through to the exact 64-bit scan below.
+        // waves of a random crowd of 64; an arena of 256 leaves 24 bits for the image: four times that) falls through to the exact
+        // 64-bit scan below.
         const float rangeSq0 = sqr(p.neighbor_dist);
         const unsigned lowmask = (unsigned)(P - 1);
         const float fx_scale = 0.999f * (float)(1u << (31 - p.logP)) * 2.0f / rangeSq0;  // image < 2^(32-logP) - 1
