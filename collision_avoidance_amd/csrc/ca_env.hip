@@ -288,7 +288,10 @@ static hipError_t launch_step_kf(ca_env* e, const StepArgs& a) {
 }
 template <int KMAX, int ST>
 static hipError_t launch_step_k(ca_env* e, const StepArgs& a) {
-    return e->fuse_nbr ? launch_step_kf<KMAX, ST, true>(e, a) : launch_step_kf<KMAX, ST, false>(e, a);
+#ifdef CA_WITH_UNFUSED_NBR   // diagnostic build: the neighbour search as a launch of its own (CA_FUSE_NBR=0 / CA_NBR_BS)
+    if (!e->fuse_nbr) return launch_step_kf<KMAX, ST, false>(e, a);
+#endif
+    return launch_step_kf<KMAX, ST, true>(e, a);
 }
 template <int KMAX, int SQ, bool ALAN>
 static const void* quad_fn_k(int BS) {
@@ -341,8 +344,11 @@ static hipError_t set_lds_attr(size_t lds) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (r != hipSuccess) return r;
     }
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KMAX, BS, ST, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#ifdef CA_WITH_UNFUSED_NBR
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KMAX, BS, ST, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
+    return r;
 }
 template <int KMAX, int ST>
 static hipError_t set_lds_attr_k(int BS, size_t lds) {
@@ -630,6 +636,9 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->grid_n = (cfg->n_arenas + e->BSn / P - 1) / (e->BSn / P);
         const char* f = getenv("CA_FUSE_NBR");  // diagnostic switch: 0 = separate neighbour kernel
         e->fuse_nbr = !(f && f[0] == '0') && e->BSn == e->BS;
+#ifndef CA_WITH_UNFUSED_NBR   // the product library has the fused form only (the stand-alone kernel: build with -DCA_WITH_UNFUSED_NBR)
+        e->fuse_nbr = true; e->BSn = e->BS; e->grid_n = e->grid;
+#endif
     }
     {
         const char* v = getenv("CA_OBS_DENSE");  // diagnostic switch: 0 = one arena per observation workgroup

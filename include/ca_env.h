@@ -33,7 +33,7 @@ extern "C" {
 #define CA_MAX_OBST_NEIGHBORS 16 /* largest supported max_obst_neighbors: RVO2 keeps every edge in range (env.py:249,
                                     301-318); 16 covers the reference's own worlds (ca_stats.obst_overflow counts the rest) */
 #define CA_MAX_AGENTS 1024       /* one workgroup owns one arena; above 256 agents max_neighbors <= 10
-                                    and max_obst_neighbors <= 4 are required (LDS capacity)              */
+                                    is required (LDS capacity: the register-line solve kernels)         */
 
 /* error codes */
 #define CA_OK 0
@@ -167,7 +167,10 @@ int ca_set_obstacles_per_arena(ca_env* env, const float* verts_xy, const int32_t
 int ca_get_obstacles_arena(ca_env* env, int32_t arena, float* verts_xy, int32_t* next, int32_t* convex, int32_t cap,
                            int32_t* n_out);
 
-/* Replaces _init_world's agent loop (env.py:86-97) / ALAN's scenario generators (ALAN:270-330). */
+/* Replaces _init_world's agent loop (env.py:86-97) / ALAN's scenario generators (ALAN:175-457).  Runs on the device: every
+ * agent's heading, start and targets come from the handle's counter-based streams (keyed by the global arena id) or, for
+ * the layouts that do not depend on the arena, from a per-agent table made once on the host (its cos / sin / sqrt are
+ * libm's); only the rejection-sampled starts of CA_SCN_CROWD_SEPARATED are drawn on the host (sequential per arena). */
 int ca_init_scenario(ca_env* env, int32_t scenario);
 
 /* Replaces the per-scalar getters/setters (sim.getAgentPosition, setAgentPosition, ...
@@ -220,7 +223,9 @@ int ca_alan_configure(ca_env* env, const double* actions_xy, int32_t n_actions, 
                       double time_step);
 int ca_alan_step(ca_env* env, const double* u, int32_t u_is_device, uint32_t flags);
 /* `steps` consecutive ca_alan_step(env, NULL, 0, flags) calls without returning to the host: with
- * CA_F_FREEZE this is run_sim(mode=1) (ALAN:106-123) for every arena at once. */
+ * CA_F_FREEZE this is run_sim(mode=1) (ALAN:106-123) for every arena at once.  Where the handle uses the four-lanes kernel
+ * (ca_solver_info: rollout_one_launch) the bandit runs INSIDE that kernel -- one launch per 256 steps, weights and times
+ * resident in LDS --, and a single ca_alan_step is one launch instead of three (select, solve, update). */
 int ca_alan_rollout(ca_env* env, int32_t steps, uint32_t flags);
 
 /* Blocks until the stream is idle, then returns the counters accumulated so far. */
@@ -252,10 +257,14 @@ int ca_profile_read(ca_env* env, int32_t counts[4], float mean_ms[4]);
 
 /* Launch geometry chosen for this handle (for reports): threads per block, blocks, LDS bytes. */
 int ca_launch_info(ca_env* env, int32_t* block, int32_t* grid, int32_t* lds_bytes, int32_t* obs_grid);
-/* Which solve kernel the handle uses: *lanes_per_agent = 1 (one lane per agent) or 4 (four lanes per agent: chosen
- * at ca_create for batches that would otherwise leave SIMDs without a wave -- fewer than 1024 waves -- when
- * n_agents <= 128 and max_neighbors <= 10 (n_agents <= 64 when, in addition, max_neighbors > 5 and max_obst_neighbors > 4);
- * results are identical bit for bit).
+/* Which solve kernel the handle uses: *lanes_per_agent = 1 (one lane per agent), 2 (two lanes per agent: arenas of 192 .. 512
+ * agents with max_neighbors <= 10 and max_obst_neighbors <= 4 -- one arena per workgroup is otherwise two waves per SIMD, each
+ * a long dependent chain) or 4 (four lanes per agent: chosen at ca_create for batches that would otherwise leave SIMDs without
+ * a wave -- fewer than 1024 waves -- when n_agents <= 128 and max_neighbors <= 10 (n_agents <= 64 when, in addition,
+ * max_neighbors > 5 and max_obst_neighbors > 4)); results are identical bit for bit.  Among the one-lane kernels the ORCA
+ * lines live in registers when max_neighbors <= 10 and either max_obst_neighbors <= 4 or the installed world has at most 16
+ * edges per arena (the reference env's own doorway world: an agent with more than four edges in range is solved apart,
+ * exactly), else in an LDS table; the choice is re-made when obstacle tables are installed.
  * *rollout_one_launch = 1: ca_rollout(env, T, flags without CA_F_OBS) is ONE kernel launch that keeps every arena in
  * registers / LDS for its T steps (the four-lanes kernel; chosen up to 1024 waves inclusive); 0: it is T launches. */
 int ca_solver_info(ca_env* env, int32_t* lanes_per_agent, int32_t* rollout_one_launch);

@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 from collision_avoidance_amd import build as b  # noqa: E402
 
 KERNELS = ("nbr_kernel", "step_kernel", "obs_kernel", "lp3_kernel")
-ALIAS = {"quad_kernel": "step_kernel"}   # the four-lanes-per-agent solve kernel is reported in the step_kernel slot (its full name is kept)
+ALIAS = {"quad_kernel": "step_kernel", "pair_kernel": "step_kernel"}   # the four- / two-lanes-per-agent solve kernels are reported in the step_kernel slot (the full name is kept)
 
 
 def means(d):
@@ -50,7 +50,7 @@ def main():
     out_path, workload, mode, A, N = sys.argv[4], sys.argv[5], sys.argv[6], int(sys.argv[7]), int(sys.argv[8])
     step_bytes = 60 if mode == "step" else 52
     alg = {"nbr_kernel": 0, "step_kernel": step_bytes * A * N, "obs_kernel": 256 * A * N, "lp3_kernel": 0}
-    out = {"src_sha": b.source_sha(), "workload": workload, "mode": mode,
+    out = {"src_sha": b.loaded_sha(), "workload": workload, "mode": mode,
            "note": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*) of `python3 bench.py --workload %s --mode %s "
                    "--steps 20 --warmup 5 --no-cpu-baseline`; means over the launches of a pass; KB per launch; "
                    "hbm_bytes_low uses FETCH_SIZE as reported, hbm_bytes_high doubles it (gfx950 tallies the 128-B "
