@@ -87,10 +87,11 @@ struct StepArgs {
     unsigned long long* dbg;  // CA_STAMPS diagnostic build only: [waves][16] phase cycle counts
     int n_obst, A, N, P, logP, K, S;
     int a0, a1;  // this launch covers arenas [a0, a1) (chunked launches on several streams)
-    // lane -> (arena slot of the workgroup, agent): arenas take P lanes each (P = power of two >= N: shift and mask), or --
-    // linv != 0: arenas within one wave whose N is not a power of two -- N lanes each, back to back (the reference env's own
-    // 10-agent arenas: six per wave instead of four); linv = ceil(2^16 / N), so that (lane * linv) >> 16 = lane / N
-    int LS, apb, linv;
+    // lane -> (arena slot of the workgroup, agent): arenas take LS lanes each -- P (the power of two >= N), or, `dense`, N
+    // lanes back to back for arenas within one wave whose N is no power of two (the reference env's own 10-agent arenas: six
+    // per wave instead of four).  One formula for both: linv = ceil(2^16 / LS), (lane * linv) >> 16 = lane / LS for every lane
+    // of a workgroup (checked by ca_create).
+    int LS, apb, linv, dense;
     int nb_hint;   // 1: the agent-neighbour lists in memory are those a solve kernel left (K distinct agents each): the pair
                    // kernel bounds its scan with them (ca_pair.h); 0 after the caller wrote the lists through ca_set
     int T;       // quad kernel, ORCA-only mode: steps advanced by this launch (ca_quad.h); 1 otherwise
@@ -109,8 +110,8 @@ __device__ __forceinline__ int work_block(const StepArgs&) { return (int)blockId
 #endif
 
 __device__ __forceinline__ void lane_slot(const StepArgs& p, int tid, int& la, int& i) {
-    if (p.linv) { la = (tid * p.linv) >> 16; i = tid - la * p.LS; }
-    else { la = tid >> p.logP; i = tid & (p.P - 1); }
+    la = (int)(__umul24((unsigned)tid, (unsigned)p.linv) >> 16);
+    i = tid - (int)__umul24((unsigned)la, (unsigned)p.LS);
 }
 
 // CA_F_FREEZE: arenas whose arena_done flag is set are left exactly as they are

@@ -64,7 +64,7 @@ struct ca_env {
     int P = 1, logP = 0, BS = 64, grid = 1, K = 0, S = 1;
     bool obs_dense_on = false;
     bool lists_trusted = true;   // the neighbour lists in memory were written by the kernels (not by the caller through ca_set)
-    int LS = 1, apb = 1, linv = 0;   // lanes per arena, arenas per workgroup, ceil(2^16 / LS) or 0 (ca_common.h StepArgs)
+    int LS = 1, apb = 1, linv = 65536, dense = 0;   // lanes per arena, arenas per workgroup, ceil(2^16 / LS), packed back to back (ca_common.h StepArgs)
     int BSn = 64, grid_n = 1;  // the neighbour kernel's own workgroup size
     bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
     int ST = 0, KT = 16;  // solve-kernel variant: ST > 0 = register lines with ST obstacle slots; KT = KMAX
@@ -229,7 +229,7 @@ static void fill_args(ca_env* e, StepArgs& a, const float* actions, uint32_t fla
     a.reset_px = nullptr; a.reset_py = nullptr; a.reset_mask = nullptr; a.dbg = e->dbg;
     a.n_obst = e->h_tab_off.empty() ? (int)e->h_obst.size() : 0; a.A = c.n_arenas; a.N = c.n_agents; a.P = e->P; a.logP = e->logP;
     a.K = e->K; a.S = e->S; a.flags = flags; a.a0 = 0; a.a1 = c.n_arenas; a.T = 1;
-    a.LS = e->LS; a.apb = e->apb; a.linv = e->linv; a.nb_hint = e->lists_trusted ? 1 : 0;
+    a.LS = e->LS; a.apb = e->apb; a.linv = e->linv; a.dense = e->dense; a.nb_hint = e->lists_trusted ? 1 : 0;
     a.time_step = c.time_step; a.neighbor_dist = c.neighbor_dist; a.time_horizon = c.time_horizon;
     a.time_horizon_obst = c.time_horizon_obst; a.radius = c.radius; a.max_speed = c.max_speed;
 }
@@ -239,7 +239,7 @@ static void launch_nbr_k(ca_env* e, const StepArgs& a_in) {
     const dim3 grid(e->grid_n), block(e->BSn);
     ProfScope ps(e, KIND_NBR);
     StepArgs a = a_in;
-    a.apb = e->BSn / e->P;   // (the stand-alone neighbour kernel may run with a workgroup size of its own: CA_NBR_BS)
+    a.apb = e->BSn / e->P; a.LS = e->P; a.linv = 65536 / e->P; a.dense = 0;   // (the stand-alone neighbour kernel may run with a workgroup size of its own: CA_NBR_BS)
     switch (e->BSn) {
         case 64: launch_k(ps, nbr_kernel<KMAX, 64, SM>, grid, block, 0, e->stream, a); break;
         case 128: launch_k(ps, nbr_kernel<KMAX, 128, SM>, grid, block, 0, e->stream, a); break;
@@ -362,7 +362,8 @@ static hipError_t set_lds_attr_k(int BS, size_t lds) {
 }
 
 typedef void (*obs_fn_t)(const ObsArgs);
-static obs_fn_t obs_fn(int obs_bs, bool w16) {  // workgroup size x width of the stored agent-neighbour ids
+static obs_fn_t obs_fn(int obs_bs, bool w16, bool dense = false) {  // workgroup size x width of the stored agent-neighbour ids
+    if (dense) return obs_kernel<256, false, true>;   // (arenas of fewer than 16 agents: 256 lanes, 8-bit ids)
     switch (obs_bs) {
         case 1024: return w16 ? obs_kernel<1024, true> : obs_kernel<1024, false>;
         case 512: return w16 ? obs_kernel<512, true> : obs_kernel<512, false>;
@@ -407,7 +408,7 @@ static hipError_t launch_obs(ca_env* e) {
     const dim3 grid(o.dense ? (unsigned)(((size_t)o.A * o.N + apb - 1) / apb) : (unsigned)((size_t)o.A * o.bpa)), block(obs_bs);
     const size_t lds = obs_lds_bytes(o.nstage_max, obs_bs, o.paircap);
     ProfScope ps(e, KIND_OBS);
-    launch_k(ps, obs_fn(obs_bs, e->nidx16 != 0), grid, block, lds, e->stream, o);
+    launch_k(ps, obs_fn(obs_bs, e->nidx16 != 0, o.dense != 0), grid, block, lds, e->stream, o);
     return hipGetLastError();
 }
 
@@ -625,7 +626,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     while (P < cfg->n_agents) { P <<= 1; ++logP; }
     e->P = P; e->logP = logP;
     e->BS = P > 64 ? P : 64;
-    e->LS = P; e->apb = e->BS / P; e->linv = 0;
+    e->LS = P; e->apb = e->BS / P; e->linv = 65536 / P; e->dense = 0;   // (P a power of two: exact)
     e->grid = (cfg->n_arenas + e->apb - 1) / e->apb;
     {
         const char* v = getenv("CA_NBR_BS");  // diagnostic switch: power of two in [max(P, 64), 1024]
@@ -653,7 +654,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
             bool exact = true;
             for (int t = 0; t < 64; ++t) exact = exact && ((t * linv) >> 16) == t / N;
             if (exact) {
-                e->LS = N; e->apb = 64 / N; e->linv = linv;
+                e->LS = N; e->apb = 64 / N; e->linv = linv; e->dense = 1;
                 e->grid = (cfg->n_arenas + e->apb - 1) / e->apb;
             }
         }
@@ -718,7 +719,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         const int obs_bs = obs_block_threads(cfg->n_agents);
         const size_t ol = obs_lds_bytes(obs_nstage(e), obs_bs, 16 * (e->K + e->S));
         if (ol > 48 * 1024) {
-            r = hipFuncSetAttribute(reinterpret_cast<const void*>(obs_fn(obs_bs, e->nidx16 != 0)),
+            r = hipFuncSetAttribute(reinterpret_cast<const void*>(obs_fn(obs_bs, e->nidx16 != 0, obs_dense(e))),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ol);
         }
     }

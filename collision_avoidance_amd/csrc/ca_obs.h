@@ -107,7 +107,7 @@ __device__ __forceinline__ float ray_dial(float x, float y) {
 // is < 1e-4 and the margin is 0.01 dial units (3.9e-3 rad).  Segments passing (almost) through the
 // origin, where "short way round" is ill-defined, get all 16 rays.  For an agent NEIGHBOUR the
 // window is that of the circle through its octagon's vertices (see the pre-pass).
-template <int OBS_BS, bool NW16>
+template <int OBS_BS, bool NW16, bool DENSE = false>
 __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     constexpr int OBS_APB = OBS_BS / 16;  // agents per workgroup
     extern __shared__ float4 smem4[];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     if (p.xcd) { const int x = bid & 7, idx = bid >> 3, q8 = idx / p.bpa; bid = (x + 8 * q8) * p.bpa + (idx - q8 * p.bpa); }
     int a, i, a_lo, nstage;   // this group's arena and agent; first arena and number of agents the workgroup stages
     bool active;
-    if (p.dense) {   // groups = consecutive agents of the batch
+    if constexpr (DENSE) {   // groups = consecutive agents of the batch
         const int first = bid * OBS_APB, gi = first + g;
         active = gi < p.A * N;
         const int ga = active ? gi : p.A * N - 1;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         active = i < N;
         a_lo = a; nstage = N;
     }
-    const int abase = (a - a_lo) * N;   // LDS index of agent 0 of this group's arena
+    const int abase = DENSE ? (a - a_lo) * N : 0;   // LDS index of agent 0 of this group's arena
     const size_t q = (size_t)a * N + (active ? i : 0);
     const ObstDev* tab = p.obst + (p.tab_off ? p.tab_off[a] : 0);  // this arena's edge table
 

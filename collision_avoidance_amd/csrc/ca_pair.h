@@ -674,7 +674,7 @@ __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
             c.arena_done[a] = all_done ? 1 : 0;
             c.step_count[a] = do_reset ? 0 : steps;
             if (do_reset) c.episode[a] = epi + 1;
-            c.arena_steps[a] += 1;
+            atomicAdd(&c.arena_steps[a], 1ull);
         }
     }
     CA_PSTAMP(11);

@@ -656,7 +656,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
             if (have_lastep) st[ST_LASTEP] = lastep;
             c.arena_done[a] = adone;
             c.step_count[a] = steps;
-            c.arena_steps[a] += acc_steps;
+            atomicAdd(&c.arena_steps[a], (unsigned long long)acc_steps);
         }
     }
 }

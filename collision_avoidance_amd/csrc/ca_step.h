@@ -524,7 +524,7 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
         const int w = P < 64 ? P : 64;
         // (the guard keeps the tree inside the arena where arenas are packed back to back -- N lanes each, N no power of two;
         // a no-op where an arena has P lanes and the lanes beyond N hold zeros)
-        for (int off = w >> 1; off > 0; off >>= 1) { const double t = __shfl_down(r, off, 64); if (p.linv == 0 || i + off < N) r += t; }
+        for (int off = w >> 1; off > 0; off >>= 1) { const double t = __shfl_down(r, off, 64); if (!p.dense || i + off < N) r += t; }
         if (active && (i & 63) == 0)
             atomicAdd(reinterpret_cast<double*>(&c.arena_stats[(size_t)a * ST_STRIDE + ST_SUMREW]), r);
     }
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
             }
             c.arena_done[a] = all_done ? 1 : 0;
             c.step_count[a] = do_reset ? 0 : steps;
-            c.arena_steps[a] += 1;
+            atomicAdd(&c.arena_steps[a], 1ull);   // (no return value: nothing waits for it at the end of the kernel)
             if (do_reset) c.episode[a] = epi + 1;
         }
     }
