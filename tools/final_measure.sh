@@ -27,7 +27,7 @@ if [ "$PART" = 1 ]; then
 fi
 if [ "$PART" = 2 ]; then
   rm -rf $O/trace_C3
-  rocprofv3 --kernel-trace --stats -d $O/trace_C3 -o trace -- python3 $R/bench.py --no-cpu-baseline --steps 2000 --warmup 200 > $O/trace_C3.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_C3 -o trace -- python3 $R/bench.py --no-cpu-baseline --steps 2000 --warmup 200 > $O/trace_C3.log 2>&1 || exit 1
   python3 $R/tools/settled_kernel_stats.py $O/trace_C3 500 > $O/kernel_stats_rocprofv3_settled.csv || exit 1
   cp $(find $O/trace_C3 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_rocprofv3_all_launches.csv
   rm -rf $O/trace_C3
@@ -39,10 +39,10 @@ if [ "$PART" = pmc ]; then
     case $W in C3) A=4096; N=64;; C5) A=256; N=512;; C2) A=1024; N=16;; esac
     CMD="python3 $R/bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline"
     rm -rf $O/pmc_$W; mkdir -p $O/pmc_$W
-    rocprofv3 --pmc FETCH_SIZE -d $O/pmc_$W/fetch -- $CMD > $O/pmc_$W/fetch.log 2>&1 || exit 1
-    rocprofv3 --pmc WRITE_SIZE -d $O/pmc_$W/write -- $CMD > $O/pmc_$W/write.log 2>&1 || exit 1
-    rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY -d $O/pmc_$W/sq1 -- $CMD > $O/pmc_$W/sq1.log 2>&1 || exit 1
-    rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_WAIT_ANY -d $O/pmc_$W/sq2 -- $CMD > $O/pmc_$W/sq2.log 2>&1 || exit 1
+    rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/pmc_$W/fetch -- $CMD > $O/pmc_$W/fetch.log 2>&1 || exit 1
+    rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/pmc_$W/write -- $CMD > $O/pmc_$W/write.log 2>&1 || exit 1
+    rocprofv3 --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY -d $O/pmc_$W/sq1 -- $CMD > $O/pmc_$W/sq1.log 2>&1 || exit 1
+    rocprofv3 --output-format csv --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_WAIT_ANY -d $O/pmc_$W/sq2 -- $CMD > $O/pmc_$W/sq2.log 2>&1 || exit 1
     (cd $R && python3 tools/counters.py $O/pmc_$W/fetch $O/pmc_$W/write $O/pmc_$W/sq1,$O/pmc_$W/sq2 $O/counters_${W}_step.json $W step $A $N) > $O/counters_${W}.log 2>&1 || exit 1
     rm -rf $O/pmc_$W
   done
