@@ -4,11 +4,17 @@
 // Why: one lane per agent turns BASELINE config C5 (256 arenas x 512 agents) into 2048 waves on a chip of 1024 SIMDs:
 // two waves per SIMD, each one long dependent chain (neighbour scan -> ten half-planes -> LP2 -> statistics) that runs
 // as slowly alone as with three co-runners (a C5 wave takes as many cycles at two waves per SIMD as a C3 wave takes at
-// four: profiles/r04_a_c5_phase_stamps.txt) -- the chip idles half of its issue slots.  Here lanes 2 s and 2 s + 1 work for
+// four: profiles/r04_a_c5_phase_stamps_and_pair_kernel.txt) -- the chip idles half of its issue slots.  Here lanes 2 s and 2 s + 1 work for
 // agent slot s, so the same arena is twice as many waves, each with a shorter chain:
-//   * the uniform-grid neighbour scan (ca_nbr.h) deals every cell row's candidates to the two lanes alternately; each keeps
-//     a sorted list of 64-bit (distance, index) keys and the two lists are merged by ONE quad-permute exchange and a bitonic
-//     network (ca_quad.h merge_with_partner): the keys are totally ordered, so the merged list IS the serial scan's;
+//   * the arena is sorted into a uniform grid in LDS (counting sort, as in ca_nbr.h; cells a quarter of the neighbour range
+//     wide) and FROM THEN ON the pair of slot s works for the agent at position s of the sorted list: a wave's 32 agents are
+//     neighbours in space -- they walk the same cell rows (candidate reads are LDS broadcasts, one trip count per wave) and
+//     need LP3 together or not at all;
+//   * the scan covers only the cells within the distance of the FARTHEST MEMBER OF THE AGENT'S PREVIOUS LIST (any K distinct
+//     agents bound the distance of the K-th nearest: a settled crowd has ~50 agents within the neighbour range of 5 and the
+//     tenth-nearest at 2.6); every cell row's candidates are dealt to the two lanes alternately, each lane keeps a sorted list
+//     of 64-bit (distance, index) keys and the two lists are merged by ONE quad-permute exchange and a bitonic network
+//     (ca_quad.h merge_with_partner): the keys are totally ordered, so the merged list IS the serial scan's;
 //   * lane h builds the half-planes of neighbours h, h + 2, ... into ITS register slots: slot m of the even lane holds
 //     neighbour 2 m, slot m of the odd lane neighbour 2 m + 1 -- ONE instruction stream builds two lines at a time;
 //   * LP2 walks the lines in the contract's order (the current line reaches both lanes by a DPP broadcast from its owner;
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
     // whole wave solves the slots, four lanes each (ca_lp.h lp3_coop).  (Dealing the arena's infeasible agents over the
     // pools of ALL its waves -- they cluster in the waves of the dense core -- was built and measured twice, before and
     // after the scan was shortened: the same kernel time, a round of lp3_coop is as long as its slowest slot whoever runs
-    // it; profiles/r04_b_c5_pair_kernel.txt.) ----
+    // it; profiles/r04_a_c5_phase_stamps_and_pair_kernel.txt.) ----
     {
         float4* pool = s_lines + (size_t)(tid >> 6) * (2 * ML) * POOL_SLOTS;
         float4* hdr = pool + (size_t)(2 * ML - 1) * POOL_SLOTS;

@@ -32,7 +32,7 @@ typedef const __attribute__((address_space(4))) StepCold ColdK;  // the cold blo
 // lane alone, exactly as the contract says -- every half-plane built in order into one contiguous LDS table (the wave's LP3
 // pool is free at that point), LP2 over it; the caller runs LP3 on the same table with lp3_coop (stride 1) if LP2 fails.
 // RVO2 keeps every edge in range (env.py:249, 301-318), so the list capacity stays 16; in the reference's doorway and
-// "congested" worlds (14 edges) no agent-step of 3.8e5 sampled had more than four (profiles/r04_c_reference_worlds.txt),
+// "congested" worlds (14 edges) no agent-step of 3.8e5 sampled had more than four (profiles/r04_b_reference_worlds.txt),
 // which is what lets those worlds run on the register-line kernel.  Not inlined: the hot path's registers are not its.
 template <bool NW16>
 __device__ __noinline__ void solve_many_obstacles(float4* tbl, int MLX, const ObstDev* tab, const unsigned short* oidx, const void* nidx,
