@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C5", "A16", "A50", "A100"])
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C5", "A16", "A50", "A100", "M128", "M180"])
     ap.add_argument("--mode", default="step", choices=["step", "orca", "alan"],
                     help="step: full env step (actions in, observation out); orca: ORCA-only rollout; alan: the ALAN online-learning "
                          "rollout of ALAN_true.py:106-123 (softmax draw -> ORCA step -> bandit update per agent and step, no observation)")

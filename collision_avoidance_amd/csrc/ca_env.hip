@@ -558,8 +558,11 @@ static void pick_variant(ca_env* e) {
     }
     {   // two lanes per agent for the whole step (ca_pair.h) where the helper lanes were: a 512-agent arena is 8 waves of one
         // lane per agent on its CU -- two per SIMD, each a long dependent chain; 16 waves with half the chain each fill it
-        const char* pv = getenv("CA_PAIR");  // diagnostic switch: 0 = the lane kernel with helper lanes in the scan
-        e->pair = e->help && !(pv && pv[0] == '0');
+        const char* pv = getenv("CA_PAIR");  // diagnostic switch: 0 = the lane kernel (with helper lanes in the scan from 192 agents)
+        const char* pm = getenv("CA_PAIR_MIN");  // diagnostic: smallest arena that takes it
+        const int pair_min = pm ? atoi(pm) : 129;   // (arenas of 65 .. 128 agents -- two waves -- measured faster on the lane kernel: ca_pair.h)
+        e->pair = !(pv && pv[0] == '0') && e->fuse_nbr && e->ST > 0 && e->SMX == 4 && (e->BS == 256 || e->BS == 512) &&
+                  e->cfg.n_agents >= pair_min && e->K > 0;
         e->lds_p = pair_lds_bytes(e->BS, e->KT);
     }
 }

@@ -266,8 +266,11 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
             scanned = true;
         }
     }
-    if (K > 0 && !scanned && N <= 256) {
-        // Arenas of at most 256 agents (brute-force scan; 8-bit agent ids): 32-bit composite keys = (fixed-point distance << logP) | candidate index and
+#ifndef CA_CK_MAXN
+#define CA_CK_MAXN 64    // the largest arena that first tries the composite keys (see below: larger arenas measured slower)
+#endif
+    if (K > 0 && !scanned && N <= CA_CK_MAXN) {
+        // Arenas of at most 64 agents: 32-bit composite keys = (fixed-point distance << logP) | candidate index and
         // one v_med3_u32 per list slot and candidate -- new[k] = med3(old[k-1], old[k], x) IS the sorted insert,
         // at half the instructions of the 64-bit network (in so small an arena some lane accepts nearly every
         // candidate, so the shrinking range of the contract never lets a wave skip the network anyway).  The
@@ -277,8 +280,9 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
         // lane whose K+1 smallest composites have pairwise different images provably holds the exact list:
         // strictly increasing images order the first K exactly and put every other candidate behind them.  A
         // wave in which some lane fails that test (exact fp32 ties, e.g. the symmetric circle world; ~2e-3 of the
-        // waves of a random crowd of 64; an arena of 256 leaves 24 bits for the image: four times that) falls through to the exact
-        // 64-bit scan below.
+        // waves of a young random crowd) falls through to the exact 64-bit scan below.  (Arenas of 65 .. 256 agents were tried in
+        // round 4 -- fewer bits of image -- and measured 15-25 % slower once the crowd has settled: it packs at exactly the
+        // contact distance 2 R, so the neighbours of an agent in its dense core share their image and most waves scan twice.)
         const float rangeSq0 = sqr(p.neighbor_dist);
         const unsigned lowmask = (unsigned)(P - 1);
         const float fx_scale = 0.999f * (float)(1u << (31 - p.logP)) * 2.0f / rangeSq0;  // image < 2^(32-logP) - 1

@@ -1,4 +1,4 @@
-// ca_pair.h -- the solve kernel with TWO LANES PER AGENT, for LARGE arenas (192 .. 512 agents per arena)
+// ca_pair.h -- the solve kernel with TWO LANES PER AGENT, for LARGE arenas (129 .. 512 agents per arena)
 // Part of the HIP kernels of libcaenv.so (see ca_kernels.h for the overview and the numerics contract).
 //
 // Why: one lane per agent turns BASELINE config C5 (256 arenas x 512 agents) into 2048 waves on a chip of 1024 SIMDs:
@@ -27,8 +27,10 @@
 //   * the infeasible agents go through the per-wave LDS pool and lp3_coop like the lane kernel's;
 //   * the per-agent scalar work (fp64 goal direction, done test, RNG) is done redundantly by the two lanes; lane 0 of a pair
 //     writes.
-// One workgroup = one arena = 2 P lanes (P = 256 or 512).  Selected by ca_create where the lane kernel used helper lanes
-// for the scan only (192 .. 512 agents, K <= 10, <= 4 obstacle neighbours; CA_PAIR=0 falls back to that variant).
+// One workgroup = one arena = 2 P lanes (P = 256 or 512).  Selected by ca_create for arenas of 129 .. 512 agents with K <= 10 and
+// <= 4 obstacle neighbours (CA_PAIR=0 falls back to the lane kernel, with helper lanes in its scan from 192 agents).  Measured
+// crossover, settled crowds, ORCA-only us per step, lane / pair: 1024 x 100 (circle) 59.2 / 67.0, 1024 x 128 65.1 / 69.4 -- arenas
+// of two waves stay on the lane kernel --, 512 x 180 71.7 / 49.2, 256 x 512 66.9 / 50.1.
 #pragma once
 #include "ca_quad.h"
 
@@ -166,7 +168,7 @@ __host__ __device__ inline size_t pair_lds_bytes(int BS, int KMAX) {
 // BS = agent slots of the workgroup = P (the arena's power-of-two size, 256 or 512); launched with 2 BS lanes
 template <int KMAX, int BS>
 __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
-    static_assert(BS == 256 || BS == 512, "one arena of 192 .. 512 agents per workgroup");
+    static_assert(BS == 256 || BS == 512, "one arena of 129 .. 512 agents per workgroup");
     constexpr int ST = 4, ML = ST + KMAX, KH = (KMAX + 1) / 2;
     constexpr int M = KMAX <= 4 ? 4 : (KMAX <= 8 ? 8 : 16);  // merge width of the neighbour lists
     constexpr int GMAX = 32;

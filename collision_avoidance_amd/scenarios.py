@@ -199,4 +199,7 @@ BENCH_CONFIGS = {
     "A16": dict(n_arenas=1024, n_agents=16, neighbor_dist=5.0, max_neighbors=10),
     "A50": dict(n_arenas=1024, n_agents=50, neighbor_dist=5.0, max_neighbors=10),
     "A100": dict(n_arenas=1024, n_agents=100, neighbor_dist=5.0, max_neighbors=10, scenario="circle"),
+    # mid-size arenas (one arena = a workgroup of two or three waves, brute-force neighbour scan): diagnostics
+    "M128": dict(n_arenas=1024, n_agents=128, neighbor_dist=5.0, max_neighbors=10),
+    "M180": dict(n_arenas=512, n_agents=180, neighbor_dist=5.0, max_neighbors=10),
 }

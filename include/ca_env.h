@@ -257,7 +257,7 @@ int ca_profile_read(ca_env* env, int32_t counts[4], float mean_ms[4]);
 
 /* Launch geometry chosen for this handle (for reports): threads per block, blocks, LDS bytes. */
 int ca_launch_info(ca_env* env, int32_t* block, int32_t* grid, int32_t* lds_bytes, int32_t* obs_grid);
-/* Which solve kernel the handle uses: *lanes_per_agent = 1 (one lane per agent), 2 (two lanes per agent: arenas of 192 .. 512
+/* Which solve kernel the handle uses: *lanes_per_agent = 1 (one lane per agent), 2 (two lanes per agent: arenas of 129 .. 512
  * agents with max_neighbors <= 10 and max_obst_neighbors <= 4 -- one arena per workgroup is otherwise two waves per SIMD, each
  * a long dependent chain) or 4 (four lanes per agent: chosen at ca_create for batches that would otherwise leave SIMDs without
  * a wave -- fewer than 1024 waves -- when n_agents <= 128 and max_neighbors <= 10 (n_agents <= 64 when, in addition,

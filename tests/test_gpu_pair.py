@@ -1,4 +1,4 @@
-"""Large arenas (192 .. 512 agents): the two-lanes-per-agent solve kernel (csrc/ca_pair.h) is the default there and the
+"""Large arenas (129 .. 512 agents): the two-lanes-per-agent solve kernel (csrc/ca_pair.h) is the default there and the
 lane kernel with helper lanes in the scan (CA_PAIR=0) its fallback -- both against the oracle, bit for bit, and against
 each other.  The pair kernel works through the arena in the order of its uniform grid, so per-agent results must not
 depend on where in that order an agent sits: actions, rewards, observation, auto-reset and per-arena freezing included."""
@@ -27,7 +27,7 @@ def _with_pair(value, fn):
 
 
 def test_pair_kernel_is_the_default_for_large_arenas_only():
-    for N, lanes in ((512, 2), (300, 2), (192, 2), (191, 1), (1000, 1)):
+    for N, lanes in ((512, 2), (300, 2), (192, 2), (129, 2), (128, 1), (1000, 1)):
         g = H.make_gpu(2 if N < 1000 else 1, N, "crowd", H.scenario_params("crowd", N), seed=1)
         assert g.launch_info()["lanes_per_agent"] == lanes, (N, g.launch_info())
         g.close()
