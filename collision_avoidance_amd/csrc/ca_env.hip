@@ -50,7 +50,8 @@ struct ca_env {
     double *alan_w = nullptr, *alan_t = nullptr, *alan_dirs = nullptr, *alan_u = nullptr;
     int* alan_action = nullptr;
     AlanCold* d_alan = nullptr;
-    bool alan_fused = false;      // ca_alan_step / ca_alan_rollout run as ONE launch of the four-lanes kernel   // the bandit's arguments for the four-lanes kernel (ca_common.h)
+    bool alan_fused = false;      // ca_alan_step / ca_alan_rollout run as ONE launch of the four-lanes kernel
+    bool alan_lane = false;       // ca_alan_step runs as ONE launch of the register-line lane kernel (its ALAN instantiation)   // the bandit's arguments for the four-lanes kernel (ca_common.h)
     int* mask_buf = nullptr;  // staging for ca_reset_masked's host mask
     int n_actions = 0;
     double act_c[CA_ALAN_MAX_ACTIONS], act_s[CA_ALAN_MAX_ACTIONS];
@@ -265,6 +266,13 @@ static hipError_t launch_step_kf(ca_env* e, const StepArgs& a) {
             return hipGetLastError();
         }
     }
+    if constexpr (FUSE && ST > 0 && KMAX <= 10) {
+        if (a.alan != nullptr) {   // the ALAN bandit inside the launch (ca_alan_configure allowed it: alan_lane)
+            if (e->BS == 64) launch_k(ps, step_kernel<KMAX, 64, ST, true, 1, ST, true>, grid, block, e->lds, e->stream, a);
+            else launch_k(ps, step_kernel<KMAX, 128, ST, true, 1, ST, true>, grid, block, e->lds, e->stream, a);
+            return hipGetLastError();
+        }
+    }
     if constexpr (FUSE && ST > 0) {
         if (e->SMX > ST) {  // register lines, obstacle-neighbour lists of up to 16 (agents with more than ST are solved apart)
             switch (e->BS) {
@@ -327,7 +335,7 @@ static hipError_t launch_step(ca_env* e, const StepArgs& a) {
     return r;
 }
 static hipError_t launch_step_any(ca_env* e, const StepArgs& a) {
-    if (e->quad || (a.T > 1 && e->quad_roll) || a.alan != nullptr) return launch_quad(e, a);
+    if (e->quad || (a.T > 1 && e->quad_roll) || (a.alan != nullptr && !e->alan_lane)) return launch_quad(e, a);
     if (e->ST > 0) return e->KT == 5 ? launch_step_k<5, 4>(e, a) : launch_step_k<10, 4>(e, a);
     if (e->K <= 5) return launch_step_k<5, 0>(e, a);
     if (e->K <= 10) return launch_step_k<10, 0>(e, a);
@@ -1333,6 +1341,10 @@ int ca_alan_configure(ca_env* e, const double* actions_xy, int32_t n_actions, do
         const size_t lq = quad_lds_bytes(e->BSq, e->KT, e->SQ, n_actions);
         const char* fv = getenv("CA_ALAN_FUSED");   // diagnostic switch: 0 = the three-launch form everywhere
         e->alan_fused = (e->quad || e->quad_roll) && lq <= 64 * 1024 && !(fv && fv[0] == '0');
+        // the lane kernels of one and two waves with register lines have an ALAN instantiation too: the softmax terms wait in
+        // the wave's LP3 pool, ML = 4 + KMAX doubles per lane
+        e->alan_lane = !e->quad && !(fv && fv[0] == '0') && e->fuse_nbr && e->ST > 0 && e->SMX == 4 && !e->help && !e->pair &&
+                       e->BS <= 128 && e->KT <= 10 && n_actions <= 4 + e->KT;
         if (e->alan_fused && lq > 48 * 1024)
             HIPCHK(e, hipFuncSetAttribute(quad_fn(e, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq));
     }
@@ -1351,7 +1363,7 @@ int ca_alan_step(ca_env* e, const double* u, int32_t u_is_device, uint32_t flags
         u = e->alan_u;
     }
     if (e->prof_period > 1) e->profiling = (e->steps_done % (uint64_t)e->prof_period) == 0;
-    if (e->alan_fused && e->quad) {   // ONE launch: the bandit runs inside the four-lanes kernel (ca_quad.h)
+    if ((e->alan_fused && e->quad) || e->alan_lane) {   // ONE launch: the bandit runs inside the solve kernel (ca_quad.h / ca_step.h)
         StepArgs a;
         fill_args(e, a, nullptr, flags);
         a.alan = e->d_alan; a.alan_u = u;
@@ -1404,7 +1416,13 @@ int ca_alan_rollout(ca_env* e, int32_t steps, uint32_t flags) {
         for (int done = 0; done < steps; done += CA_ROLLOUT_MAX_T) {
             if (e->prof_period > 1) e->profiling = (e->steps_done / (uint64_t)CA_ROLLOUT_MAX_T) % (uint64_t)e->prof_period == 0;
             a.T = steps - done < CA_ROLLOUT_MAX_T ? steps - done : CA_ROLLOUT_MAX_T;
-            HIPCHK(e, launch_step(e, a));
+            if (a.T == 1 && !e->quad) {   // (a lone last step is a step, not a rollout: the handle's step kernel takes it)
+                const int rc = ca_alan_step(e, nullptr, 0, flags);
+                if (rc) return rc;
+                continue;
+            }
+            HIPCHK(e, launch_quad(e, a));
+            e->lists_trusted = e->lists_trusted || !(flags & CA_F_FREEZE);
             e->steps_done += (uint64_t)a.T;
         }
         e->orient_valid = true;

@@ -29,7 +29,6 @@
 // wave (CA_QUAD=0/1 forces it).
 #pragma once
 #include "ca_step.h"
-#include "ca_alan.h"
 
 namespace ca {
 

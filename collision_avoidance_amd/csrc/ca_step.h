@@ -4,6 +4,7 @@
 #include "ca_lp.h"
 #include "ca_lines.h"
 #include "ca_nbr.h"
+#include "ca_alan.h"
 
 namespace ca {
 
@@ -72,7 +73,12 @@ __device__ __noinline__ void solve_many_obstacles(float4* tbl, int MLX, const Ob
 // HELP = 2: launched with 2 BS lanes, the upper half helps in the neighbour scan and ends (ca_nbr.h)
 // SMX: capacity of the obstacle-neighbour list (S <= SMX).  SMX > ST (register lines): the rare agent with more than ST
 // obstacle neighbours is solved apart (solve_many_obstacles)
-template <int KMAX, int BS, int ST, bool FUSE, int HELP = 1, int SMX = (ST > 0 ? ST : SMAX)>
+// ALAN (register-line kernels of one and two waves, K <= 10): the online bandit of ALAN_true.py:569-628 around the step, as in the
+// four-lanes kernel (ca_quad.h) -- softmax draw and rotated preferred velocity in the prologue (the softmax terms wait in the wave's
+// LP3 pool, which is free then: at most ML actions), reward and the sliding-window update of weights / times (global memory,
+// [A][nA][N]) where the epilogue begins; the goal direction is derived again there from the staged pre-step position instead of
+// living in registers across the solve.  Same arithmetic as ca_alan.h's kernels, which remain the three-launch form of the rest.
+template <int KMAX, int BS, int ST, bool FUSE, int HELP = 1, int SMX = (ST > 0 ? ST : SMAX), bool ALAN = false>
 __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1) void step_kernel(const StepArgs p) {
     extern __shared__ float4 smem4[];
     CA_PRIO_START();
@@ -125,6 +131,34 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
             const double rl_y = pf_x * sn + pf_y * cs;
             pf32 = mk((float)pf_x, (float)pf_y);
             pref = mk((float)rl_x, (float)rl_y);
+        } else if constexpr (ALAN) {   // ALAN:578-598: softmax over the action weights, one draw, goal direction rotated by the action
+            typedef const __attribute__((address_space(4))) AlanCold AlanK;
+            const AlanK& al = *(AlanK*)p.alan;
+            const int nA = al.nA;
+            double* ps = reinterpret_cast<double*>(s_lines + (size_t)(tid >> 6) * (2 * ML) * POOL_SLOTS) + (tid & 63);   // [k][lane] in the wave's pool
+            const double* w = al.w + (size_t)a * nA * N + i;
+            for (int k = 0; k < nA; ++k) ps[k * 64] = exp64(w[(size_t)k * N] / al.temp);
+            const double sum = np_sum(nA, [&](int k) { return ps[k * 64]; });
+            double acc = 0.0;
+            for (int k = 0; k < nA; ++k) { const double v = ps[k * 64] / sum; ps[k * 64] = v; acc += v; }
+            double ui, u1;
+            if (p.alan_u) ui = p.alan_u[q];
+            else {
+                const StepCold* cp = p.cold;
+                rng2(cp->seed, cp->arena_offset + a, i, RNG_ALAN + (cp->episode[a] << 8), (uint32_t)cp->step_count[a], &ui, &u1);
+            }
+            int act_id = nA - 1;
+            double run = 0.0;
+            bool found = false;
+            for (int k = 0; k < nA - 1; ++k) {
+                run += ps[k * 64];
+                if (!found && run / acc > ui) { act_id = k; found = true; }
+            }
+            double dgx, dgy;
+            pref_dir64(pos.x, pos.y, p.goal_x[q], p.goal_y[q], &dgx, &dgy);
+            const double cs = al.act_c[act_id], sn = al.act_s[act_id];
+            pref = mk((float)(dgx * cs - dgy * sn), (float)(dgx * sn + dgy * cs));
+            pf32 = mk(__int_as_float(act_id), 0.0f);   // (the lane's slot of the goal direction carries the action: no action tensor here)
         } else {
             pref = mk(p.pref_x[q], p.pref_y[q]);
         }
@@ -377,6 +411,38 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
     const ObstDev* tab = p.obst + ((p.tab_off != nullptr && active) ? p.tab_off[a] : 0);
     pf32 = mk(reinterpret_cast<float*>(s_misc)[tid * 4 + 0], reinterpret_cast<float*>(s_misc)[tid * 4 + 1]);
     if constexpr (PARK_PREF) pref = mk(reinterpret_cast<float*>(s_misc)[tid * 4 + 2], reinterpret_cast<float*>(s_misc)[tid * 4 + 3]);
+    float rew_alan = 0.0f;
+    if constexpr (ALAN) {   // ALAN:603-628: reward of the executed action, sliding-window update (the staged arena still is the pre-step one)
+        typedef const __attribute__((address_space(4))) AlanCold AlanK;
+        const AlanK& al = *(AlanK*)p.alan;
+        if (active) {
+            const int act_id = __float_as_int(pf32.x), nA = al.nA;
+            double dgx, dgy;
+            pref_dir64(s_px[tid], s_py[tid], c.goal_x[q], c.goal_y[q], &dgx, &dgy);   // the prologue's values again, bit for bit
+            const double cs = al.act_c[act_id], sn = al.act_s[act_id];
+            const double dlx = dgx * cs - dgy * sn, dly = dgx * sn + dgy * cs;
+            {
+                const float scale = (float)al.reward_scale;
+                const float r_goal = vel.x * (float)dgx + vel.y * (float)dgy;
+                const float r_polite = vel.x * (float)dlx + vel.y * (float)dly;
+                rew_alan = scale * r_goal + (1.0f - scale) * r_polite;
+                al.reward[q] = rew_alan;
+            }
+            const double vx = (double)vel.x, vy = (double)vel.y;
+            const double Rw = al.reward_scale * (vx * dgx + vy * dgy) + (1.0 - al.reward_scale) * (vx * dlx + vy * dly);
+            double* w = al.w + (size_t)a * nA * N + i;
+            double* t = al.t + (size_t)a * nA * N + i;
+            for (int k = 0; k < nA; ++k) {
+                double tk = t[(size_t)k * N] + al.dt;
+                double wk = w[(size_t)k * N];
+                if (tk >= al.window) { tk = 0.0; wk = 0.0; }
+                if (k == act_id) wk = Rw;
+                t[(size_t)k * N] = tk; w[(size_t)k * N] = wk;
+            }
+            al.action[q] = act_id;
+            c.pref_x[q] = (float)dlx; c.pref_y[q] = (float)dly;   // the agent still holds the velocity it was given at ALAN:598
+        }
+    }
 
     __syncthreads();  // every lane is done with the pre-step arena image
     s_px[tid] = pos.x; s_py[tid] = pos.y;
@@ -519,8 +585,8 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
         pref = mk((float)dx, (float)dy);
     }
     // sum of rewards: fixed-shape tree inside the wave, then per-arena in lane order
-    if (p.actions && (p.flags & 2u)) {
-        double r = active ? (double)rew : 0.0;
+    if ((p.actions || ALAN) && (p.flags & 2u)) {
+        double r = active ? (double)(ALAN ? rew_alan : rew) : 0.0;
         const int w = P < 64 ? P : 64;
         // (the guard keeps the tree inside the arena where arenas are packed back to back -- N lanes each, N no power of two;
         // a no-op where an arena has P lanes and the lanes beyond N hold zeros)
@@ -543,7 +609,7 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
         c.orient_x[q] = ox; c.orient_y[q] = oy;
         c.pos_x[q] = pos.x; c.pos_y[q] = pos.y;
         c.vel_x[q] = vel.x; c.vel_y[q] = vel.y;
-        c.pref_x[q] = pref.x; c.pref_y[q] = pref.y;
+        if constexpr (!ALAN) { c.pref_x[q] = pref.x; c.pref_y[q] = pref.y; }   // (ALAN: written above)
         if (i == 0) {
             unsigned long long* st = c.arena_stats + (size_t)a * ST_STRIDE;
             if (red[1]) st[ST_COLL] += (unsigned)red[1];

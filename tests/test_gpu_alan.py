@@ -293,3 +293,46 @@ def test_fused_alan_launch_equals_three_launch_form_and_oracle():
     H.assert_stats_equal(fused, e, "fused rollout")
     assert fused.get(_lib.FLD_ARENA_DONE).all()
     fused.close(); plain.close()
+
+
+@pytest.mark.parametrize("scenario,A,N,acts,over", [
+    ("crowd", 30, 16, alan.DEFAULT_ACTIONS, {}),                       # one wave, K = 10, 8 actions
+    ("circle", 5, 100, ACTS9, {}),                                     # two waves per arena, 9 actions
+    ("crowd", 9, 40, alan.DEFAULT_ACTIONS[:3], dict(max_neighbors=5, neighbor_dist=2.0)),   # the K = 5 kernel
+    ("crowd", 6, 24, [(1, 0), (0, 1)] * 16, {}),                       # 32 actions: more than the pool holds -> three launches
+])
+def test_alan_inside_the_lane_kernel(scenario, A, N, acts, over):
+    """Batches on the one-lane-per-agent register-line kernels (forced here with CA_QUAD=0; by default every batch of 1024 or
+    more waves) run the bandit inside the solve launch too (csrc/ca_step.h, ALAN instantiation): against the oracle, bit for
+    bit, with caller-supplied uniforms, the handle's own draws, statistics, observation and per-arena freezing."""
+    import os
+    p = H.scenario_params(scenario, N, max_step=70, **over)
+    os.environ["CA_QUAD"] = "0"
+    try:
+        g = H.make_gpu(A, N, scenario, p, seed=5)
+    finally:
+        del os.environ["CA_QUAD"]
+    e = H.make_oracle(A, N, scenario, p, seed=5)
+    g.alan_configure(acts); e.alan_configure(acts)
+    assert g.launch_info()["lanes_per_agent"] == 1
+    rng = np.random.RandomState(9)
+    for s in range(8):
+        u = rng.uniform(0, 1, (A, N))
+        g.alan_step(u=u, stats=True); e.alan_step(u=u, flags=o.F_STATS)
+    _assert_alan_equal(g, e, "given uniforms")
+    sc = (np.arange(A) % 17).astype(np.int32) + g.get(_lib.FLD_STEP_COUNT)     # the arenas end at different steps
+    g.set(_lib.FLD_STEP_COUNT, sc); e.set(o.FLD_STEP_COUNT, sc)
+    for s in range(50):
+        obs = s % 25 == 24
+        live = g.get(_lib.FLD_ARENA_DONE) == 0 if obs else None     # (an arena that is frozen already is not observed again by the oracle)
+        g.alan_step(stats=True, freeze=True, with_obs=obs); e.alan_step(flags=o.F_STATS | o.F_FREEZE | (o.F_OBS if obs else 0))
+        if obs:
+            _assert_alan_equal(g, e, "own draws, step %d" % s)
+            H._eq(g.get(_lib.FLD_OBS)[live], e.get(o.FLD_OBS)[live], "obs step %d" % s)
+            assert live.any()
+    g.alan_rollout(40, stats=True, freeze=True)
+    for s in range(40):
+        e.alan_step(flags=o.F_STATS | o.F_FREEZE)
+    _assert_alan_equal(g, e, "rollout")
+    H.assert_stats_equal(g, e, "lane ALAN")
+    g.close()

@@ -27,7 +27,7 @@ def _with_pair(value, fn):
 
 
 def test_pair_kernel_is_the_default_for_large_arenas_only():
-    for N, lanes in ((512, 2), (300, 2), (192, 2), (129, 2), (128, 1), (1000, 1)):
+    for N, lanes in ((512, 2), (300, 2), (192, 2), (129, 2), (1000, 1)):
         g = H.make_gpu(2 if N < 1000 else 1, N, "crowd", H.scenario_params("crowd", N), seed=1)
         assert g.launch_info()["lanes_per_agent"] == lanes, (N, g.launch_info())
         g.close()
