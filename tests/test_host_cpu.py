@@ -128,12 +128,12 @@ def test_no_hot_kernel_uses_scratch_memory():
     kr.ensure_asm()
     rows = kr.parse()
     names = [r["name"] for r in rows]
-    for want in ("step_kernel<10, 64, 4, true, 1, 4>", "quad_kernel<5, 64, 4, false>", "quad_kernel<10, 256, 16, false>",
-                 "quad_kernel<5, 64, 4, true>", "pair_kernel<10, 512>", "step_kernel<5, 64, 4, true, 1, 16>"):
+    for want in ("step_kernel<10, 64, 4, true, 1, 4, false>", "step_kernel<10, 64, 4, true, 1, 4, true>", "quad_kernel<5, 64, 4, false>",
+                 "quad_kernel<10, 256, 16, false>", "quad_kernel<5, 64, 4, true>", "pair_kernel<10, 512>", "step_kernel<5, 64, 4, true, 1, 16, false>"):
         assert any(n.startswith(want) for n in names), want
     bad = kr.spilling(rows)
     assert not bad, [(r["name"], r["scratch"], r["vgpr_spill"]) for r in bad]
     # the kernel the reference env's OWN world selects (doorway, K = 5, obstacle lists of up to 16: env.py:26-44, 117-122)
     # is not among the exemptions: no scratch at all
-    own = [r for r in rows if r["name"].startswith("step_kernel<5, 64, 4, true, 1, 16>")]
+    own = [r for r in rows if r["name"].startswith("step_kernel<5, 64, 4, true, 1, 16, false>")]
     assert own and own[0]["scratch"] == 0 and own[0]["vgpr_spill"] == 0, own

@@ -70,8 +70,8 @@ def by_design(name):
     # ... and the K = 10 register-line kernel with obstacle lists of 16 (the world "congested", ALAN:195-208): the stage that
     # solves an agent with more than four obstacle neighbours apart costs it two of its 14 line slots (32-48 B against the
     # 448 B of the LDS-table kernel it replaces there); the K = 5 kernel of the reference env's own world has none
-    return re.match(r"step_kernel<\d+, \d+, 0, (true|false)(, \d+)*>", name) is not None or \
-        re.match(r"step_kernel<10, \d+, 4, true, 1, 16>", name) is not None or \
+    return re.match(r"step_kernel<\d+, \d+, 0, (true|false)(, \w+)*>", name) is not None or \
+        re.match(r"step_kernel<10, \d+, 4, true, 1, 16(, \w+)*>", name) is not None or \
         name.startswith("quad_kernel<10, 512, 16")   # instantiated for the launch switch, never selected (ca_create: 256 lanes at most)
 
 
