@@ -18,7 +18,7 @@ if [ "$PART" = 1 ]; then
     $B --workload $W > $O/bench_${W}.json 2>> $O/err.txt || exit 1
     $B --workload $W --mode orca > $O/bench_${W}_orca.json 2>> $O/err.txt || exit 1
   done
-  for W in A16 A50 A100; do
+  for W in A16 A50 A100 C3; do
     $B --mode alan --workload $W --steps 1000 --warmup 200 --cpu-seconds 6 > $O/bench_alan_${W}.json 2>> $O/err.txt || exit 1
   done
   $B --variant free --no-cpu-baseline > $O/bench_C3_step_free.json 2>> $O/err.txt || exit 1
