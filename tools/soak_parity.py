@@ -21,10 +21,14 @@ cases = [("crowd", 64, scenarios.bench_params(64, 5.0, 10), 11), ("crowd", 64, s
          ("crowd", 16, scenarios.bench_params(16, 1.5, 5), 7), ("deadlock", 30, H.scenario_params("deadlock", 30), 9),
          ("crowd", 256, scenarios.bench_params(256, 5.0, 10), 13),
          ("blocks", 12, H.scenario_params("blocks", 12), 15),            # a world per arena
-         ("crowd_separated", 64, scenarios.bench_params(64, 5.0, 10), 17)]
+         ("crowd_separated", 64, scenarios.bench_params(64, 5.0, 10), 17),
+         # round 4: the two-lanes kernel (arenas of 129 .. 512 agents: grid order, scan bounded by the previous list), the
+         # register-line kernel with obstacle lists of 16 (K = 10 world of 14 edges), a mid-size arena on the lane kernel
+         ("crowd", 512, scenarios.bench_params(512, 5.0, 10), 19), ("crowd", 180, scenarios.bench_params(180, 5.0, 10), 21),
+         ("congested", 24, H.scenario_params("congested", 24), 23), ("crowd", 100, scenarios.bench_params(100, 5.0, 10), 25)]
 for scen, N, p, seed in cases:
     t0 = time.time()
-    A_case = A if N <= 64 else max(8, A // 16)
+    A_case = A if N <= 64 else max(8, A // 16 if N <= 256 else A // 64)
     g = H.make_gpu(A_case, N, scen, p, seed=seed)
     e = H.make_oracle(A_case, N, scen, p, seed=seed)
     rng = np.random.RandomState(seed)
