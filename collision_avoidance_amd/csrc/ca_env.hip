@@ -1512,8 +1512,8 @@ int ca_reset_stats(ca_env* e) {
 }
 
 int ca_debug_math(ca_env* e, int32_t op, const void* in, void* out, int32_t n) {
-    if (!e || !in || !out || n <= 0 || op < 0 || op > 5) return fail(e, CA_EINVAL, "ca_debug_math: bad argument");
-    static const size_t in_b[] = {4, 8, 8, 16, 16, 8}, out_b[] = {4, 4, 16, 16, 16, 8};
+    if (!e || !in || !out || n <= 0 || op < 0 || op > 7) return fail(e, CA_EINVAL, "ca_debug_math: bad argument");
+    static const size_t in_b[] = {4, 8, 8, 16, 16, 8, 8, 4}, out_b[] = {4, 4, 16, 16, 16, 8, 4, 4};
     HIPCHK(e, hipSetDevice(e->device));
     void *di = nullptr, *dout = nullptr;
     HIPCHK(e, hipMalloc(&di, in_b[op] * n));

@@ -60,6 +60,10 @@ __global__ void debug_math_kernel(int op, const void* in, void* out, int n, uint
         ((double*)out)[2 * t] = a; ((double*)out)[2 * t + 1] = b;
     } else if (op == 5) {
         ((double*)out)[t] = exp64(((const double*)in)[t]);
+    } else if (op == 6) {
+        ((float*)out)[t] = div_ir(((const float*)in)[2 * t], ((const float*)in)[2 * t + 1]);
+    } else if (op == 7) {
+        ((float*)out)[t] = sqrt_ir(((const float*)in)[t]);
     }
 }
 

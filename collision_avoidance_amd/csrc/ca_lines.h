@@ -27,14 +27,14 @@ __device__ __forceinline__ Line agent_orca_line(V2 pos, V2 vel, V2 opos, V2 ovel
     const float dp1 = dot(w, rp);
     const bool circle = coll || (dp1 < 0.0f && sqr(dp1) > crSq * wLenSq);
     // cut-off circle / collision
-    const float wLen = sqrtf(wLenSq);
-    const V2 unitW = vdiv(w, wLen);
+    const float wLen = sqrt_ir(wLenSq);   // (0 or >= 1e-16: squares of differences of O(1) fp32 values)
+    const V2 unitW = vdiv_ir(w, wLen);   // (wLen: 0 -- NaN either way, as the contract's 0 / 0 -- or >= 1e-8: differences of O(1) fp32 values)
     const V2 uC = (cr * invX - wLen) * unitW;
     // legs
-    const float leg = sqrtf(distSq - crSq);
+    const float leg = sqrt_ir(distSq - crSq);   // (used where positive: >= an ulp of 1; negative -> NaN, unused)
     const bool left = det(rp, w) > 0.0f;
     const float c = left ? cr : -cr;
-    V2 dirL = vdiv(mk(rp.x * leg - rp.y * c, rp.x * c + rp.y * leg), distSq);
+    V2 dirL = vdiv_ir(mk(rp.x * leg - rp.y * c, rp.x * c + rp.y * leg), distSq);   // (used for distSq > (2 R)^2 only)
     dirL = left ? dirL : -dirL;
     const float dp2 = dot(rv, dirL);
     const V2 uL = dp2 * dirL - rv;
@@ -65,7 +65,7 @@ __device__ __forceinline__ bool obst_orca_line4(const ObstDev* __restrict__ tab,
     if (covered(invTO * rp1, invTO * rp2)) return false;
     const float distSq1 = absSq(rp1), distSq2 = absSq(rp2), radiusSq = sqr(R);
     const V2 ov = o2p - o1p;
-    const float s = dot(-rp1, ov) / absSq(ov);
+    const float s = div_ir(dot(-rp1, ov), absSq(ov));   // (an edge has a length)
     const float distSqLine = absSq(-rp1 - s * ov);
     if (s < 0.0f && distSq1 <= radiusSq) {
         if (o1c) {
@@ -87,26 +87,26 @@ __device__ __forceinline__ bool obst_orca_line4(const ObstDev* __restrict__ tab,
     if (s < 0.0f && distSqLine <= radiusSq) {
         if (!o1c) return false;
         o2p = o1p; o2u = o1u; o2c = o1c; same = true;  // o2 <- o1
-        const float leg1 = sqrtf(distSq1 - radiusSq);
-        leftLeg = vdiv(mk(rp1.x * leg1 - rp1.y * R, rp1.x * R + rp1.y * leg1), distSq1);
-        rightLeg = vdiv(mk(rp1.x * leg1 + rp1.y * R, -rp1.x * R + rp1.y * leg1), distSq1);
+        const float leg1 = sqrt_ir(distSq1 - radiusSq);   // (no collision with the vertex in this branch: positive)
+        leftLeg = vdiv_ir(mk(rp1.x * leg1 - rp1.y * R, rp1.x * R + rp1.y * leg1), distSq1);
+        rightLeg = vdiv_ir(mk(rp1.x * leg1 + rp1.y * R, -rp1.x * R + rp1.y * leg1), distSq1);
     } else if (s > 1.0f && distSqLine <= radiusSq) {
         if (!o2c) return false;
         lnu = o1u;                                     // the new o1's prev vertex is the old o1
         o1p = o2p; o1u = o2u; o1c = o2c; same = true;  // o1 <- o2
-        const float leg2 = sqrtf(distSq2 - radiusSq);
-        leftLeg = vdiv(mk(rp2.x * leg2 - rp2.y * R, rp2.x * R + rp2.y * leg2), distSq2);
-        rightLeg = vdiv(mk(rp2.x * leg2 + rp2.y * R, -rp2.x * R + rp2.y * leg2), distSq2);
+        const float leg2 = sqrt_ir(distSq2 - radiusSq);
+        leftLeg = vdiv_ir(mk(rp2.x * leg2 - rp2.y * R, rp2.x * R + rp2.y * leg2), distSq2);
+        rightLeg = vdiv_ir(mk(rp2.x * leg2 + rp2.y * R, -rp2.x * R + rp2.y * leg2), distSq2);
     } else {
         if (o1c) {
-            const float leg1 = sqrtf(distSq1 - radiusSq);
-            leftLeg = vdiv(mk(rp1.x * leg1 - rp1.y * R, rp1.x * R + rp1.y * leg1), distSq1);
+            const float leg1 = sqrt_ir(distSq1 - radiusSq);
+            leftLeg = vdiv_ir(mk(rp1.x * leg1 - rp1.y * R, rp1.x * R + rp1.y * leg1), distSq1);
         } else {
             leftLeg = -o1u;
         }
         if (o2c) {
-            const float leg2 = sqrtf(distSq2 - radiusSq);
-            rightLeg = vdiv(mk(rp2.x * leg2 + rp2.y * R, -rp2.x * R + rp2.y * leg2), distSq2);
+            const float leg2 = sqrt_ir(distSq2 - radiusSq);
+            rightLeg = vdiv_ir(mk(rp2.x * leg2 + rp2.y * R, -rp2.x * R + rp2.y * leg2), distSq2);
         } else {
             rightLeg = o1u;
         }
@@ -123,15 +123,15 @@ __device__ __forceinline__ bool obst_orca_line4(const ObstDev* __restrict__ tab,
     const V2 leftCut = invTO * (o1p - pos);
     const V2 rightCut = invTO * (o2p - pos);
     const V2 cutVec = rightCut - leftCut;
-    const float t = same ? 0.5f : dot(vel - leftCut, cutVec) / absSq(cutVec);
+    const float t = same ? 0.5f : div_ir(dot(vel - leftCut, cutVec), absSq(cutVec));   // (not `same`: the cut-off segment has a length)
     const float tLeft = dot(vel - leftCut, leftLeg);
     const float tRight = dot(vel - rightCut, rightLeg);
     if ((t < 0.0f && tLeft < 0.0f) || (same && tLeft < 0.0f && tRight < 0.0f)) {
-        const V2 unitW = normalize(vel - leftCut);
+        const V2 unitW = normalize_ir(vel - leftCut);
         CA_SET_LINE(leftCut + R * invTO * unitW, mk(unitW.y, -unitW.x));
         return true;
     } else if (t > 1.0f && tRight < 0.0f) {
-        const V2 unitW = normalize(vel - rightCut);
+        const V2 unitW = normalize_ir(vel - rightCut);
         CA_SET_LINE(rightCut + R * invTO * unitW, mk(unitW.y, -unitW.x));
         return true;
     }

@@ -33,7 +33,7 @@ __device__ __forceinline__ bool lp1(const LS& ls, int lineNo, float radius, V2 o
     const float dp = dot(L.point, L.dir);
     const float disc = sqr(dp) + sqr(radius) - absSq(L.point);
     if (disc < 0.0f) return false;
-    const float sq = sqrtf(disc);
+    const float sq = sqrt_ir(disc);   // (disc = 0 or >= an ulp of O(1) terms; negative: the lane has failed already / fails below)
     float tLeft = -dp - sq;
     float tRight = -dp + sq;
     bool failed = false;
@@ -41,7 +41,7 @@ __device__ __forceinline__ bool lp1(const LS& ls, int lineNo, float radius, V2 o
         const float den = det(L.dir, M.dir);
         const float num = det(M.dir, L.point - M.point);
         const bool par = fabsf(den) <= EPS;
-        const float t = num / den;
+        const float t = div_ir(num, den);   // (used only where |den| > EPS: den in (1e-5, 1], num = 0 or in [1e-21, 5e7])
         const bool right = !par && den >= 0.0f, left = !par && !(den >= 0.0f);
         tRight = (right && t < tRight) ? t : tRight;
         tLeft = (left && tLeft < t) ? t : tLeft;
@@ -71,7 +71,7 @@ __device__ __forceinline__ bool lp1(const LS& ls, int lineNo, float radius, V2 o
 template <class LS>
 __device__ __forceinline__ int lp2(const LS& ls, int n, float radius, V2 opt, bool dirOpt, V2& result) {
     if (dirOpt) result = opt * radius;
-    else if (absSq(opt) > sqr(radius)) result = normalize(opt) * radius;
+    else if (absSq(opt) > sqr(radius)) result = normalize_ir(opt) * radius;   // (|opt| > radius here)
     else result = opt;
     for (int i = 0; i < n; ++i) {
         const Line L = ls.get(i);
@@ -107,9 +107,9 @@ __device__ __noinline__ void lp3(LdsLines ls, int n, int numObst, int begin, flo
                     if (dot(Li.dir, Lj.dir) > 0.0f) continue;
                     l.point = 0.5f * (Li.point + Lj.point);
                 } else {
-                    l.point = Li.point + (det(Lj.dir, Li.point - Lj.point) / d) * Li.dir;
+                    l.point = Li.point + div_ir(det(Lj.dir, Li.point - Lj.point), d) * Li.dir;   // (|d| > EPS here)
                 }
-                l.dir = normalize(Lj.dir - Li.dir);
+                l.dir = normalize_ir(Lj.dir - Li.dir);   // (unit vectors that are not parallel: |difference| in [1e-5, 2]; parallel ones are skipped or opposite)
                 proj[m++] = l;
             }
             const V2 tmp = result;
@@ -147,7 +147,7 @@ __device__ __forceinline__ bool lp1_reg(const float4 (&L)[ML], int no, float rad
     const float dp = dot(Li.point, Li.dir);
     const float disc = sqr(dp) + sqr(radius) - absSq(Li.point);
     if (disc < 0.0f) return false;
-    const float sq = sqrtf(disc);
+    const float sq = sqrt_ir(disc);   // (disc = 0 or >= an ulp of O(1) terms; negative: the lane has failed already / fails below)
     float tLeft = -dp - sq;
     float tRight = -dp + sq;
     bool failed = false;
@@ -158,7 +158,7 @@ __device__ __forceinline__ bool lp1_reg(const float4 (&L)[ML], int no, float rad
             const float den = det(Li.dir, M.dir);
             const float num = det(M.dir, Li.point - M.point);
             const bool par = fabsf(den) <= EPS;
-            const float t = num / den;
+            const float t = div_ir(num, den);   // (used only where |den| > EPS: den in (1e-5, 1], num = 0 or in [1e-21, 5e7])
             // (bitwise operators on purpose: with && / || the compiler builds branches around single moves -- 546 branches and
             // 4 754 scalar instructions in the K = 10 kernel against 374 and 3 407 this way)
             const bool pos = den >= 0.0f;
@@ -183,7 +183,7 @@ template <int ML, int ST, class OptFn>
 __device__ __forceinline__ int lp2_reg(const float4 (&L)[ML], int no, int ncnt, float radius, OptFn opt_fn, V2& result) {
     {
         const V2 opt = opt_fn();
-        if (absSq(opt) > sqr(radius)) result = normalize(opt) * radius;
+        if (absSq(opt) > sqr(radius)) result = normalize_ir(opt) * radius;   // (|opt| > radius here)
         else result = opt;
     }
     int fail = no + ncnt;
@@ -256,9 +256,9 @@ __device__ __noinline__ void lp3_coop(float4* pool, int ML, int nslots, float ra
                         if (dot(Li.dir, Lj.dir) > 0.0f) valid = false;
                         else l.point = 0.5f * (Li.point + Lj.point);
                     } else {
-                        l.point = Li.point + (det(Lj.dir, Li.point - Lj.point) / d) * Li.dir;
+                        l.point = Li.point + div_ir(det(Lj.dir, Li.point - Lj.point), d) * Li.dir;   // (|d| > EPS here)
                     }
-                    l.dir = normalize(Lj.dir - Li.dir);
+                    l.dir = normalize_ir(Lj.dir - Li.dir);   // (unit vectors that are not parallel: |difference| in [1e-5, 2]; parallel ones are skipped or opposite)
                 }
                 const unsigned mask = (unsigned)(__ballot(valid) >> gshift) & 0xFu;
                 if (valid) pj.put(m + __popc(mask & ((1u << q) - 1u)), l);
@@ -274,7 +274,7 @@ __device__ __noinline__ void lp3_coop(float4* pool, int ML, int nslots, float ra
                     const float dp = dot(L.point, L.dir);
                     const float disc = sqr(dp) + sqr(radius) - absSq(L.point);
                     int failed = disc < 0.0f ? 1 : 0;
-                    const float sq = sqrtf(disc);
+                    const float sq = sqrt_ir(disc);   // (disc = 0 or >= an ulp of O(1) terms; negative: the lane has failed already / fails below)
                     float tLeft = -dp - sq;
                     float tRight = -dp + sq;
                     for (int jj = q; jj < ii; jj += 4) {
@@ -282,7 +282,7 @@ __device__ __noinline__ void lp3_coop(float4* pool, int ML, int nslots, float ra
                         const float den = det(L.dir, M.dir);
                         const float num = det(M.dir, L.point - M.point);
                         const bool par = fabsf(den) <= EPS;
-                        const float t = num / den;
+                        const float t = div_ir(num, den);   // (used only where |den| > EPS: den in (1e-5, 1], num = 0 or in [1e-21, 5e7])
                         const bool right = !par && den >= 0.0f, left = !par && !(den >= 0.0f);
                         tRight = (right && t < tRight) ? t : tRight;
                         tLeft = (left && tLeft < t) ? t : tLeft;

@@ -25,10 +25,55 @@ CA_HD float det(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
 CA_HD float absSq(V2 a) { return a.x * a.x + a.y * a.y; }
 CA_HD float sqr(float a) { return a * a; }
 CA_HD float vabs(V2 a) { return sqrtf(absSq(a)); }
+// a / b, IEEE-correct, for operands AWAY FROM THE ENDS OF THE EXPONENT RANGE.  The compiler's correctly rounded fp32 division is
+// eleven instructions on gfx950: v_div_scale x 2 (pre-scale numerator / denominator by 2^+-64 when the quotient would leave the
+// normal range), v_rcp, six FMAs of Newton refinement and residual correction (the last one v_div_fmas, which undoes the scaling),
+// v_div_fixup (infinities, NaNs, zeros).  For 2^-60 <= |b| <= 2^60 and a = 0 or 2^-60 <= |a| <= 2^60 the scale and fix-up
+// instructions are the identity, so the remaining eight ARE that sequence and return its bits -- the correctly rounded quotient,
+// what the oracle's host division returns.  Used where the operands of every lane whose result is USED are in range by
+// construction (the callers say why); a lane outside the range gets some value or NaN and must not use it.
+// tests/test_gpu_parity.py::test_numerics_contract_division_in_range: 2e9 pairs against the host's division.
+CA_HD float div_ir(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e0 = __builtin_fmaf(-b, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float q0 = a * r1;
+    const float e1 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(e2, r1, q1);
+#else
+    return a / b;
+#endif
+}
+// sqrt(x), IEEE-correct, for x = 0 or x >= 2^-96: the compiler's correctly rounded fp32 square root (v_sqrt_f32, then the
+// choice among the result and its two neighbours by the signs of two FMA residuals) without its pre-scaling of tiny arguments
+// and its class fix-up: 9 instructions instead of 16.  A correctly rounded result is unique, so these are the bits of the host's
+// sqrtf.  (0, +inf and NaN come out right as well; a negative argument gives a NaN.)
+// tests/test_gpu_parity.py::test_numerics_contract_sqrt_in_range.
+CA_HD float sqrt_ir(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float y = __builtin_amdgcn_sqrtf(x);
+    const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
+    const float rm = __builtin_fmaf(-ym, y, x), rp = __builtin_fmaf(-yp, y, x);
+    y = (rm <= 0.0f) ? ym : y;
+    y = (rp > 0.0f) ? yp : y;
+    return y;
+#else
+    return sqrtf(x);
+#endif
+}
 CA_HD V2 vdiv(V2 a, float s) {  // vector / scalar multiplies by the reciprocal
     const float inv = 1.0f / s;
     return mk(a.x * inv, a.y * inv);
 }
+// ... with the reciprocal through div_ir: for s in [2^-60, 2^60] (or a result that is not used)
+CA_HD V2 vdiv_ir(V2 a, float s) {
+    const float inv = div_ir(1.0f, s);
+    return mk(a.x * inv, a.y * inv);
+}
+CA_HD V2 normalize_ir(V2 a) { return vdiv_ir(a, sqrt_ir(a.x * a.x + a.y * a.y)); }   // (|a| = 0 -- NaN either way -- or in [2^-48, 2^48])
 CA_HD V2 normalize(V2 a) { return vdiv(a, vabs(a)); }
 CA_HD float leftOf(V2 a, V2 b, V2 c) { return det(a - c, b - a); }
 CA_HD float distSqPointSegment(V2 a, V2 b, V2 c) {

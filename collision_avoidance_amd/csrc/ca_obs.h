@@ -302,9 +302,9 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         if ((s_numer < 0.0f) == dpos) return false;
         if ((sg.t_numer < 0.0f) == dpos) return false;
         if (((s_numer > denom) == dpos) || ((sg.t_numer > denom) == dpos)) return false;
-        const float t = sg.t_numer / denom;                            // utils.py:34
+        const float t = div_ir(sg.t_numer, denom);                     // utils.py:34 (an accepted crossing: 0 <= t <= 1, |denom| >= an ulp of O(1) products)
         hx = 0.0f + t * s10x; hy = 0.0f + t * s10y;                    // utils.py:36-37
-        d = sqrtf(hx * hx + hy * hy);                                  // utils.py:38
+        d = sqrt_ir(hx * hx + hy * hy);                                // utils.py:38
         return true;
     };
 
@@ -317,9 +317,9 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
                ((s_numer > denom) != dpos) && ((sg.t_numer > denom) != dpos);  // utils.py:15-31
     };
     auto hit_dist = [&](float t_numer, float denom, float s10x, float s10y) -> float {
-        const float t = t_numer / denom;                               // utils.py:34
+        const float t = div_ir(t_numer, denom);                        // utils.py:34 (used for accepted crossings only: see hit())
         const float hx = 0.0f + t * s10x, hy = 0.0f + t * s10y;        // utils.py:36-37
-        return sqrtf(hx * hx + hy * hy);                               // utils.py:38
+        return sqrt_ir(hx * hx + hy * hy);                             // utils.py:38
     };
 
     // ---- phase A: lane per (source, ray) pair ----
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         float wx, wy;
         build((int)(unsigned)key, sg, wx, wy, true);
         const float s10x = s_rays[2 * r] - 0.0f, s10y = s_rays[2 * r + 1] - 0.0f;
-        const float t = sg.t_numer / (s10x * sg.s32y - sg.s32x * s10y);  // utils.py:14,34: the accepted hit again
+        const float t = div_ir(sg.t_numer, s10x * sg.s32y - sg.s32x * s10y);  // utils.py:14,34: the accepted hit again
         bx = 0.0f + t * s10x; by = 0.0f + t * s10y;                      // utils.py:36-37
         if (!(bx == 0.0f && by == 0.0f)) { vx = wx; vy = wy; }  // utils.py:103
     }

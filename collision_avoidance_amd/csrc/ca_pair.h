@@ -56,7 +56,7 @@ struct Clip {
         const float den = det(Li.dir, M.dir);
         const float num = det(M.dir, Li.point - M.point);
         const bool par = fabsf(den) <= EPS;
-        const float t = num / den;
+        const float t = div_ir(num, den);   // (ca_lp.h lp1_reg: in range wherever it is used)
         const bool pos = den >= 0.0f;
         const bool right = valid & !par & pos, left = valid & !par & !pos;
         tRight = (right & (t < tRight)) ? t : tRight;
@@ -81,7 +81,7 @@ __device__ __forceinline__ int lp2_pair(const float4 (&OB)[4], const float4 (&OB
                                         int h, float radius, OptFn opt_fn, V2& result) {
     {
         const V2 opt = opt_fn();
-        if (absSq(opt) > sqr(radius)) result = normalize(opt) * radius;
+        if (absSq(opt) > sqr(radius)) result = normalize_ir(opt) * radius;   // (|opt| > radius here)
         else result = opt;
     }
     int fail = no + ncnt;
@@ -106,7 +106,7 @@ __device__ __forceinline__ int lp2_pair(const float4 (&OB)[4], const float4 (&OB
                 const float disc = sqr(dp) + sqr(radius) - absSq(Li.point);
                 bool ok = !(disc < 0.0f);
                 if (ok) {
-                    const float sq = sqrtf(disc);
+                    const float sq = sqrt_ir(disc);
                     Clip c; c.tLeft = -dp - sq; c.tRight = -dp + sq; c.failed = false;
                     if constexpr (pidx >= 1) c(Li, OBP[0], h < pidx);        // obstacle lines 0 / 1
                     if constexpr (pidx >= 3) c(Li, OBP[1], 2 + h < pidx);    // obstacle line 2 (3 is this one)
@@ -126,7 +126,7 @@ __device__ __forceinline__ int lp2_pair(const float4 (&OB)[4], const float4 (&OB
                 const float disc = sqr(dp) + sqr(radius) - absSq(Li.point);
                 bool ok = !(disc < 0.0f);
                 if (ok) {
-                    const float sq = sqrtf(disc);
+                    const float sq = sqrt_ir(disc);
                     Clip c; c.tLeft = -dp - sq; c.tRight = -dp + sq; c.failed = false;
                     if (__builtin_amdgcn_ballot_w64(no > 0) != 0ull) {   // (interior waves have no obstacle line at all)
                         c(Li, OBP[0], h < no);

@@ -104,7 +104,7 @@ __device__ __forceinline__ int pick4_index(const double (&key)[M], int q) {
 // App. A.5 LP2 (dirOpt = false) for the quad's slot of the wave's line table: `n` lines in the contract's order at
 // ls.get(0 .. n-1).  Every lane of the quad holds the same `result`; returns the index of the first infeasible line or n.
 __device__ __forceinline__ int lp2_quad(const LdsLines& ls, int n, int q, float radius, V2 opt, V2& result) {
-    if (absSq(opt) > sqr(radius)) result = normalize(opt) * radius;
+    if (absSq(opt) > sqr(radius)) result = normalize_ir(opt) * radius;   // (|opt| > radius here)
     else result = opt;
     int fail = n;
     Line L = ls.get(0);  // (row 0 exists in LDS whatever n is)
@@ -115,7 +115,7 @@ __device__ __forceinline__ int lp2_quad(const LdsLines& ls, int n, int q, float 
             const float dp = dot(Li.point, Li.dir);
             const float disc = sqr(dp) + sqr(radius) - absSq(Li.point);
             int failed = disc < 0.0f ? 1 : 0;
-            const float sq = sqrtf(disc);
+            const float sq = sqrt_ir(disc);
             float tLeft = -dp - sq;
             float tRight = -dp + sq;
             for (int jj = q; jj < i; jj += 4) {
@@ -123,7 +123,7 @@ __device__ __forceinline__ int lp2_quad(const LdsLines& ls, int n, int q, float 
                 const float den = det(Li.dir, M.dir);
                 const float num = det(M.dir, Li.point - M.point);
                 const bool par = fabsf(den) <= EPS;
-                const float t = num / den;
+                const float t = div_ir(num, den);   // (ca_lp.h lp1_reg: in range wherever it is used)
                 const bool right = !par && den >= 0.0f, left = !par && !(den >= 0.0f);
                 tRight = (right && t < tRight) ? t : tRight;
                 tLeft = (left && tLeft < t) ? t : tLeft;

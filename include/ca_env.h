@@ -240,6 +240,8 @@ int ca_sync(ca_env* env);
  * op 3: pref_dir64          in f32[4n]       out f64[2n]
  * op 4: philox4x32 uniform  in u32[4n]       out f64[2n]   (key = seed of the handle)
  * op 5: exp64(x)            in f64[n]        out f64[n]
+ * op 6: a / b by the in-range sequence (csrc/ca_math.h div_ir)   in f32[2n]   out f32[n]
+ * op 7: sqrt(x) by the in-range sequence (csrc/ca_math.h sqrt_ir) in f32[n]    out f32[n]
  * Host pointers. */
 int ca_debug_math(ca_env* env, int32_t op, const void* in, void* out, int32_t n);
 

@@ -20,7 +20,7 @@ def dbg():
 
 
 def _debug(env, op, inp, out):
-    env._call("ca_debug_math", env.h, op, inp.ctypes.data, out.ctypes.data, len(out) if op < 2 else len(out) // 2)
+    env._call("ca_debug_math", env.h, op, inp.ctypes.data, out.ctypes.data, len(out) if op < 2 or op >= 6 else len(out) // 2)
 
 
 def test_numerics_contract_sqrt_div(dbg):
@@ -34,6 +34,58 @@ def test_numerics_contract_sqrt_div(dbg):
     _debug(dbg, 1, ab, out)
     with np.errstate(all="ignore"):
         np.testing.assert_array_equal(out, ab[:, 0] / ab[:, 1])
+
+
+def test_numerics_contract_division_in_range(dbg):
+    """csrc/ca_math.h div_ir: the compiler's correctly rounded fp32 division minus its range scaling and fix-up instructions,
+    used where the operands are in range by construction (LP1 clips, the reciprocals of the half-planes).  It must return the
+    bits of IEEE division -- the oracle's host division -- for every pair of its domain: 2e8 pairs here (random mantissas with
+    exponents over the whole domain 2^-60 .. 2^60, numerators that are exact multiples, quotients next to a rounding
+    boundary, a zero numerator); tools/diag/div_exhaustive.py runs 2e9."""
+    rng = np.random.RandomState(7)
+    n = 1 << 22
+    for rnd in range(48):
+        mant = lambda: (rng.randint(0, 1 << 23, n).astype(np.uint32) | np.uint32(0x3F800000)).view(np.float32)    # [1, 2)
+        ea, eb = rng.randint(-60, 61, n), rng.randint(-60, 61, n)
+        if rnd % 4 == 1:      # the ranges of the LP1 clip: den in (1e-5, 1], num in [1e-21, 240]
+            ea, eb = rng.randint(-70, 8, n), rng.randint(-17, 1, n)
+        b = np.ldexp(mant(), eb).astype(np.float32) * rng.choice(np.float32([-1, 1]), n)
+        a = np.ldexp(mant(), ea).astype(np.float32) * rng.choice(np.float32([-1, 1]), n)
+        if rnd % 4 == 2:      # quotients that sit next to a rounding boundary: a = fl(q * b) for a random q, then one ulp either way
+            q = np.ldexp(mant(), rng.randint(-20, 21, n)).astype(np.float32)
+            a = np.nextafter((q * b).astype(np.float32), np.float32(np.inf) * rng.choice(np.float32([-1, 1]), n)).astype(np.float32)
+        if rnd % 4 == 3:      # exact quotients and a zero numerator
+            a = (b * rng.randint(-4096, 4097, n).astype(np.float32)).astype(np.float32)
+        ab = np.ascontiguousarray(np.stack([a, b], 1))
+        out = np.empty(n, np.float32)
+        _debug(dbg, 6, ab, out)
+        with np.errstate(all="ignore"):
+            ref = (a / b).astype(np.float32)
+        bad = out.view(np.uint32) != ref.view(np.uint32)
+        assert not bad.any(), (rnd, int(bad.sum()), a[bad][:3], b[bad][:3], out[bad][:3], ref[bad][:3])
+
+
+def test_numerics_contract_sqrt_in_range(dbg):
+    """csrc/ca_math.h sqrt_ir: the compiler's correctly rounded square root without its scaling of tiny arguments and its class
+    fix-up; domain x = 0 or x >= 2^-96.  The bits of IEEE sqrt for 1.3e8 arguments: every exponent of the domain with random
+    mantissas, the squares of random numbers and their two neighbours (the rounding boundaries), 0 and +inf."""
+    rng = np.random.RandomState(8)
+    n = 1 << 22
+    for rnd in range(32):
+        m = (rng.randint(0, 1 << 23, n).astype(np.uint32) | np.uint32(0x3F800000)).view(np.float32)
+        x = np.ldexp(m, rng.randint(-96, 120, n)).astype(np.float32)
+        if rnd % 4 == 1:
+            y = np.ldexp(m, rng.randint(-40, 40, n)).astype(np.float32)
+            x = (y * y).astype(np.float32)
+            x = np.where(rng.randint(0, 3, n) == 0, x, np.nextafter(x, np.float32(np.inf) * rng.choice(np.float32([-1, 1]), n))).astype(np.float32)
+        if rnd % 4 == 2:      # the range of the discriminants and squared lengths of the solver
+            x = np.ldexp(m, rng.randint(-54, 16, n)).astype(np.float32)
+        x[:4] = [0.0, np.inf, 1.0, 2.0 ** -96]
+        out = np.empty(n, np.float32)
+        _debug(dbg, 7, np.ascontiguousarray(x), out)
+        ref = np.sqrt(x).astype(np.float32)
+        bad = out.view(np.uint32) != ref.view(np.uint32)
+        assert not bad.any(), (rnd, int(bad.sum()), x[bad][:3], out[bad][:3], ref[bad][:3])
 
 
 def test_numerics_contract_fp64_helpers(dbg):
