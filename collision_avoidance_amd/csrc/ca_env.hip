@@ -791,6 +791,8 @@ static int build_table(ca_env* e, const float* verts_xy, const int32_t* poly_siz
             const V2 pt = mk(verts_xy[2 * (off + i)], verts_xy[2 * (off + i) + 1]);
             const V2 pn = mk(verts_xy[2 * (off + in)], verts_xy[2 * (off + in) + 1]);
             const V2 pp = mk(verts_xy[2 * (off + ip)], verts_xy[2 * (off + ip) + 1]);
+            if (pn.x == pt.x && pn.y == pt.y)
+                return fail(e, CA_EINVAL, "ca_set_obstacles: polygon %d has an edge of length zero (vertex %d twice)", pi, i);
             const V2 u = normalize(pn - pt);
             ObstDev o;
             memset(&o, 0, sizeof o);

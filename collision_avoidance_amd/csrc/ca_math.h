@@ -76,8 +76,9 @@ CA_HD V2 vdiv_ir(V2 a, float s) {
 CA_HD V2 normalize_ir(V2 a) { return vdiv_ir(a, sqrt_ir(a.x * a.x + a.y * a.y)); }   // (|a| = 0 -- NaN either way -- or in [2^-48, 2^48])
 CA_HD V2 normalize(V2 a) { return vdiv(a, vabs(a)); }
 CA_HD float leftOf(V2 a, V2 b, V2 c) { return det(a - c, b - a); }
+// (the segment is an obstacle edge: ca_set_obstacles refuses edges of length zero, so the division is in div_ir's range)
 CA_HD float distSqPointSegment(V2 a, V2 b, V2 c) {
-    const float r = dot(c - a, b - a) / absSq(b - a);
+    const float r = div_ir(dot(c - a, b - a), absSq(b - a));
     if (r < 0.0f) return absSq(c - a);
     if (r > 1.0f) return absSq(c - b);
     return absSq(c - (a + r * (b - a)));

@@ -98,7 +98,7 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
         auto visit = [&](const ObstDev& o1, int e, bool mine) __attribute__((always_inline)) {
             const V2 a1 = mk(o1.px, o1.py), a2 = mk(o1.qx, o1.qy);
             const float alol = leftOf(a1, a2, pos);
-            const float dsl = sqr(alol) / absSq(a2 - a1);
+            const float dsl = div_ir(sqr(alol), absSq(a2 - a1));   // (an edge has a length; the quotient is only compared with the range)
             if (mine && dsl < rangeSq && alol < 0.0f) {
                 const float dsq = distSqPointSegment(a1, a2, pos);
                 if (dsq < rangeSq) {

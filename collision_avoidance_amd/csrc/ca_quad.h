@@ -322,7 +322,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
                 const ObstDev o1 = load_obst(tab, mine ? e : 0);
                 const V2 a1 = mk(o1.px, o1.py), a2 = mk(o1.qx, o1.qy);
                 const float alol = leftOf(a1, a2, pos);
-                const float dsl = sqr(alol) / absSq(a2 - a1);
+                const float dsl = div_ir(sqr(alol), absSq(a2 - a1));   // (an edge has a length; the quotient is only compared with the range)
                 const float dsq = distSqPointSegment(a1, a2, pos);
                 const bool in = mine && dsl < rangeSq && alol < 0.0f && dsq < rangeSq;
                 oin += in ? 1 : 0;
