@@ -209,136 +209,6 @@ __device__ __forceinline__ int lp2_reg(const float4 (&L)[ML], int no, int ncnt, 
 
 constexpr int POOL_SLOTS = 16;  // LP3 pool slots per wave (lanes beyond that take another round)
 
-// ---- LP1 WITH ITS CLIPS DEALT OVER THE WAVE --------------------------------------------------------------------------------
-// In a dense arena some lane violates nearly every line, so a wave executes lp1_reg<i> -- i clips of ~28 instructions -- at
-// nearly every position i while only ~6 of its 64 lanes need it (lane utilisation of LP2: ~10 %).  Here the few lanes that need
-// LP1 at position I ("owners") publish their lines 0 .. I in the wave's LP3 pool (free during LP2), every lane of the wave takes
-// ONE (owner, earlier line) clip, and the clips merge into the owner's interval with LDS integer min / max on order-preserving
-// images of the floats: tRight is a minimum, tLeft a maximum, the parallel-line failure an OR -- all independent of the order, so
-// the interval is the sequential loop's (its running `tLeft > tRight` test equals the test on the final values, because tLeft only
-// grows and tRight only shrinks).  One round of clips instead of I.  (The one thing the order can show in is the SIGN OF A ZERO:
-// among clips that are equal as numbers -- +0 and -0, lines through one point -- the sequential loop keeps the first, the merge the
-// smaller image.  A zero's sign can reach an output only as the sign of a zero velocity component; no value depends on it.)
-#ifndef CA_DEAL_MIN_K
-#define CA_DEAL_MIN_K 3   // positions with at least this many earlier neighbour lines deal their clips (0 = never: lp1_reg everywhere)
-#endif
-__device__ __forceinline__ unsigned f2ord(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
-__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
-
-// `mine`: this lane's line I is violated.  Every lane of the wave calls it (wave-uniformly); returns LP1's verdict for the lanes
-// with `mine` (and updates their `result`), true for the others.
-template <int ML, int ST, int I, class OptFn>
-__device__ __forceinline__ bool lp1_dealt(const float4 (&L)[ML], int no, bool mine, float radius, OptFn opt_fn, V2& result, float4* pool) {
-    constexpr int K1 = I - ST;      // earlier neighbour lines
-    constexpr int ROW = I + 2;      // float4 per owner: lines 0 .. I, then (tRight, tLeft as ordered images, failed, no)
-    constexpr int CAP = (2 * ML * POOL_SLOTS) / ROW < 64 ? (2 * ML * POOL_SLOTS) / ROW : 64;   // owners per chunk of the pool
-    const int lane = threadIdx.x & 63;
-    const Line Li = unpack_line(L[I]);
-    const float dp = dot(Li.point, Li.dir);
-    const float disc = sqr(dp) + sqr(radius) - absSq(Li.point);
-    const bool own = mine && !(disc < 0.0f);   // (a negative discriminant fails at once)
-    const float sq = sqrt_ir(disc);
-    float tLeft = -dp - sq, tRight = -dp + sq;
-    bool failed = false;
-    const unsigned long long om = __ballot(own);
-    const int V = __popcll(om);
-    const int rank = __popcll(om & ((1ull << lane) - 1ull));
-    // obstacle slots in play: the largest obstacle-line count among the owners
-    const int NO = __ballot(own && no >= 4) != 0ull ? 4 : (__ballot(own && no >= 3) != 0ull ? 3 : (__ballot(own && no >= 2) != 0ull ? 2 : (__ballot(own && no >= 1) != 0ull ? 1 : 0)));
-    const int per = NO + K1;        // clips per owner: obstacle slots 0 .. NO - 1 (an owner with fewer skips the rest), neighbour slots 0 .. K1 - 1
-    const float rper = __builtin_amdgcn_rcpf((float)per);
-    for (int c0 = 0; c0 < V; c0 += CAP) {
-        const int nown = V - c0 < CAP ? V - c0 : CAP;
-        const bool pub = own && rank >= c0 && rank < c0 + CAP;
-        float4* row = pool + (pub ? rank - c0 : 0) * ROW;
-        if (pub) {
-            static_for<I + 1>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; row[j] = L[j]; });
-            row[I + 1] = make_float4(__uint_as_float(f2ord(tRight)), __uint_as_float(f2ord(tLeft)), __int_as_float(0), __int_as_float(no));
-        }
-        wave_lds_sync();
-        const int T = nown * per;
-        for (int t0 = 0; t0 < T; t0 += 64) {
-            const int t = t0 + lane;
-            if (t < T) {
-                const int r = (int)(((float)t + 0.5f) * rper);   // t / per (exact: the margin is 0.5 / per >= 0.035)
-                const int tl = t - r * per;
-                const int slot = tl < NO ? tl : ST + (tl - NO);
-                float4* orow = pool + r * ROW;
-                if (slot >= ST || slot < __float_as_int(orow[I + 1].w)) {   // an earlier line that exists
-                    const Line Lo = unpack_line(orow[I]), M = unpack_line(orow[slot]);
-                    const float den = det(Lo.dir, M.dir);
-                    const float num = det(M.dir, Lo.point - M.point);
-                    const bool par = fabsf(den) <= EPS;
-                    const float tq = div_ir(num, den);   // (used only where |den| > EPS: see lp1_reg)
-                    unsigned* res = reinterpret_cast<unsigned*>(orow + (I + 1));
-                    if (par) { if (num < 0.0f) atomicOr(&res[2], 1u); }
-                    else if (den >= 0.0f) atomicMin(&res[0], f2ord(tq));
-                    else atomicMax(&res[1], f2ord(tq));
-                }
-            }
-        }
-        wave_lds_sync();
-        if (pub) {
-            const float4 hd = row[I + 1];
-            tRight = ord2f(__float_as_uint(hd.x)); tLeft = ord2f(__float_as_uint(hd.y)); failed = __float_as_int(hd.z) != 0;
-        }
-        wave_lds_sync();   // (a further chunk rewrites the rows)
-    }
-    if (!mine) return true;
-    if (disc < 0.0f) return false;
-    if (failed | (tLeft > tRight)) return false;
-    const V2 opt = opt_fn();
-    const float t = dot(Li.dir, opt - Li.point);
-    if (t < tLeft) result = Li.point + tLeft * Li.dir;
-    else if (t > tRight) result = Li.point + tRight * Li.dir;
-    else result = Li.point + t * Li.dir;
-    return true;
-}
-
-// lp2_reg with the LP1s of the later positions dealt over the wave.  EVERY lane of the wave calls it; `take_part` = this lane has a
-// linear program of its own (the others only lend their lanes to the dealt clips and return no + ncnt).
-template <int ML, int ST, class OptFn>
-__device__ __forceinline__ int lp2_reg_dealt(const float4 (&L)[ML], int no, int ncnt, float radius, OptFn opt_fn, V2& result, float4* pool, bool take_part) {
-    {
-        const V2 opt = opt_fn();
-        if (absSq(opt) > sqr(radius)) result = normalize_ir(opt) * radius;   // (|opt| > radius here)
-        else result = opt;
-    }
-    int fail = no + ncnt;
-    bool alive = take_part;
-    static_for<ML>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int i = decltype(ic)::value;
-        const bool valid = (i < ST) ? (i < no) : (i - ST < ncnt);
-        if constexpr (i == ST + (ML - ST) / 2) CA_PRIO_POINT(4);
-        if constexpr (CA_DEAL_MIN_K > 0 && i - ST >= CA_DEAL_MIN_K) {
-            const Line Li = unpack_line(L[i]);
-            const bool viol = alive && valid && det(Li.dir, Li.point - result) > 0.0f;
-            if (__ballot(viol) != 0ull) {   // wave-uniform
-                const V2 tmp = result;
-                const bool ok = lp1_dealt<ML, ST, i>(L, no, viol, radius, opt_fn, result, pool);
-                if (viol && !ok) {
-                    result = tmp;
-                    fail = no + (i - ST);
-                    alive = false;
-                }
-            }
-        } else {
-            if (alive && valid) {
-                const Line Li = unpack_line(L[i]);
-                if (det(Li.dir, Li.point - result) > 0.0f) {
-                    const V2 tmp = result;
-                    if (!lp1_reg<ML, ST, i>(L, no, radius, opt_fn, result)) {
-                        result = tmp;
-                        fail = (i < ST) ? i : no + (i - ST);
-                        alive = false;
-                    }
-                }
-            }
-        }
-    });
-    return fail;
-}
-
 // App. A.5 LP3, FOUR LANES PER AGENT.  LP3 is needed by ~9 % of the agents of a dense crowd, i.e. by five or six
 // lanes of every wave, while it is the longest dependent computation of the step: solved one agent per lane it
 // keeps a wave busy at a tenth of its width.  Here the agents that need it sit in the wave's LDS pool (lines,

@@ -261,11 +261,6 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
             if constexpr (PARK_PREF) return mk(reinterpret_cast<const float*>(s_misc)[tid * 4 + 2], reinterpret_cast<const float*>(s_misc)[tid * 4 + 3]);
             else return pref;
         };
-#if CA_DEAL_MIN_K > 0
-        if constexpr (BS == 64 && !ALAN)   // (the one-wave shape first: the experiment's subject)
-            fail = lp2_reg_dealt<ML, ST>(L, no, ncnt, p.max_speed, opt_fn, nv, s_lines + (size_t)(tid >> 6) * (2 * ML) * POOL_SLOTS, fast);
-        else
-#endif
         if (fast) fail = lp2_reg<ML, ST>(L, no, ncnt, p.max_speed, opt_fn, nv);
         CA_STAMP(6);
         CA_PRIO_POINT(5);
