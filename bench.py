@@ -216,7 +216,9 @@ def main():
         local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # CA_BENCH_FORCE_PG=1 (rehearsal, tests/test_gpu_dist.py): a world of one still initialises the process group, so the
+    # one-GPU box takes the barriers and the all_gather through RCCL exactly as a rank of an 8-GPU job does
+    if world > 1 or os.environ.get("CA_BENCH_FORCE_PG") == "1":
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -415,9 +417,9 @@ def main():
             "launch": env.launch_info(),
             "src_sha": _b.loaded_sha(),      # compiled into the library that ran (ca_source_sha)
             "src_sha_on_disk": _b.source_sha(),
-            "backend": backend if world > 1 else None,
+            "backend": backend if dist is not None else None,
             "collectives": {"data_path": 0, "job": "one all_gather of the per-rank record (statistics, device, dt)",
-                            "timing_barriers": 2 if world > 1 else 0},
+                            "timing_barriers": 2 if dist is not None else 0},
         }
         if per_step_calls is not None:
             out["orca_per_step_calls"] = {"value": world * per_step_calls, "unit": "agent-steps/s",

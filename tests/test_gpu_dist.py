@@ -52,3 +52,23 @@ def test_gloo_ranks_drive_the_hip_library(world, arenas):
     # every rank ran the HIP kernels: the launch geometry is that of its shard; the line names the code that ran
     assert job["launch"] == singles[0]["launch"]
     assert job["src_sha"] == singles[0]["src_sha"] == job["src_sha_on_disk"] != "unknown"
+
+
+@pytest.mark.gpu
+def test_rccl_carries_the_barriers_and_the_record_in_a_world_of_one():
+    """The production backend itself ("nccl" = RCCL) on the one-GPU box: a world of one rank initialises the process group on
+    its device, takes both timing barriers and the job's one all_gather (an int64 record on the GPU) through RCCL --
+    the calls every rank of the 8-GPU job makes, which the gloo rehearsals above do not touch."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    wl = ("--workload", "C2", "--arenas", "256")
+    env = {"CA_BENCH_FORCE_PG": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
+           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+    job = _bench([], env, wl)
+    assert job["backend"] == "nccl" and job["world_size"] == 1 and job["collectives"]["timing_barriers"] == 2
+    assert job["ranks"] == [{"rank": 0, "device": 0, "agent_steps": 256 * 16 * STEPS}]
+    single = _bench([], {}, wl)
+    for k in INT_KEYS:
+        assert job["stats"][k] == single["stats"][k], (k, job["stats"], single["stats"])
