@@ -71,6 +71,7 @@ struct ca_env {
     int ST = 0, KT = 16;  // solve-kernel variant: ST > 0 = register lines with ST obstacle slots; KT = KMAX
     int SMX = 4;          // ... and the capacity of its obstacle-neighbour list (4, or 16: agents with more than ST are solved apart)
     int max_edges = 0;    // edges of the largest installed obstacle table (the variant depends on it: pick_variant)
+    int n_cus = 256;      // compute units of the device (pick_variant: is the batch resident with the LDS line table?)
     bool help = false;     // large arenas: helper lanes in the uniform-grid neighbour scan (ca_nbr.h, HELP = 2)
     bool pair = false;     // large arenas: two lanes per agent for the whole step (ca_pair.h); replaces `help` where chosen
     size_t lds_p = 0;
@@ -266,10 +267,20 @@ static hipError_t launch_step_kf(ca_env* e, const StepArgs& a) {
             return hipGetLastError();
         }
     }
-    if constexpr (FUSE && ST > 0 && KMAX <= 10) {
-        if (a.alan != nullptr) {   // the ALAN bandit inside the launch (ca_alan_configure allowed it: alan_lane)
-            if (e->BS == 64) launch_k(ps, step_kernel<KMAX, 64, ST, true, 1, ST, true>, grid, block, e->lds, e->stream, a);
-            else launch_k(ps, step_kernel<KMAX, 128, ST, true, 1, ST, true>, grid, block, e->lds, e->stream, a);
+    if constexpr (FUSE && KMAX <= 10) {
+        if (a.alan != nullptr) {   // the ALAN bandit inside the launch (alan_pick allowed it: alan_lane)
+            if constexpr (ST > 0) {
+                if (e->SMX > ST) {   // (obstacle-neighbour lists of up to 16: "congested", the doorway world)
+                    if (e->BS == 64) launch_k(ps, step_kernel<KMAX, 64, ST, true, 1, 16, true>, grid, block, e->lds, e->stream, a);
+                    else launch_k(ps, step_kernel<KMAX, 128, ST, true, 1, 16, true>, grid, block, e->lds, e->stream, a);
+                } else {
+                    if (e->BS == 64) launch_k(ps, step_kernel<KMAX, 64, ST, true, 1, ST, true>, grid, block, e->lds, e->stream, a);
+                    else launch_k(ps, step_kernel<KMAX, 128, ST, true, 1, ST, true>, grid, block, e->lds, e->stream, a);
+                }
+            } else {                 // (the LDS line table: "deadlock", "blocks")
+                if (e->BS == 64) launch_k(ps, step_kernel<KMAX, 64, 0, true, 1, SMAX, true>, grid, block, e->lds, e->stream, a);
+                else launch_k(ps, step_kernel<KMAX, 128, 0, true, 1, SMAX, true>, grid, block, e->lds, e->stream, a);
+            }
             return hipGetLastError();
         }
     }
@@ -349,6 +360,11 @@ static hipError_t set_lds_attr(size_t lds) {
     if (r != hipSuccess) return r;
     if constexpr (ST > 0) {
         r = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KMAX, BS, ST, true, 1, 16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (r != hipSuccess) return r;
+    }
+    if constexpr (ST == 0 && KMAX <= 10 && BS <= 128) {   // the ALAN instantiation of the LDS line table (two waves: 57 KB)
+        r = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<KMAX, BS, 0, true, 1, SMAX, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (r != hipSuccess) return r;
     }
@@ -539,7 +555,8 @@ static size_t lds_static_bytes(const ca_env* e) {
 //     after processObstacles, env.py:117-122; "congested", ALAN:195-208) -- there an agent practically never has more than
 //     four edges in range (none in 3.8e5 sampled agent-steps of either world), and the one that does is solved apart, exactly
 //     (ca_step.h solve_many_obstacles), so the list capacity stays RVO2's "every edge in range" --, or
-//   * the LDS line table would not fit (arenas above 256 agents with many obstacle neighbours).
+//   * the LDS line table would not fit (arenas above 256 agents with many obstacle neighbours), or the batch would not be resident
+//     with it (below).
 // Else the LDS line table (ST = 0): worlds like the two-way tube ("deadlock": 42 edges, 17 % of the agent-steps with more
 // than four in range).  Called by ca_create (no table yet) and again whenever tables are installed: every variant computes
 // the same bits, so a handle may change variant between steps.
@@ -555,8 +572,21 @@ static void pick_variant(ca_env* e) {
         e->help = h0;
     }
     const bool small_world = e->max_edges <= 16;
+    // ... or the batch is larger than the chip holds at once WITH the table: a 64-lane workgroup of the table kernel needs 28 KB of
+    // LDS (K = 10, S = 16), five fit a CU, and from the 1281st workgroup on the launch runs in rounds of a kernel that is a third
+    // occupied -- there the register lines win even in the two-way tube, where every sixth agent is solved apart (measured:
+    // deadlock x 50 agents, 1280 arenas 49.6 us (table) / 64.8 us (registers) per ORCA step, 1536 arenas 81.6 / 67.7, 4096 arenas
+    // 157.8 / 76.3; blocks x 20 agents, 8192 arenas 126.9 / 75.4; profiles/r04_g_many_edge_worlds.txt)
+    bool table_resident = table_fits;
+    if (table_fits) {
+        const bool h0 = e->help;
+        e->help = false;
+        const size_t per_wg = step_lds_bytes(e->BS, e->K, e->S, 0, e->KT) + lds_static_bytes(e);
+        e->help = h0;
+        table_resident = (long)e->grid <= (long)e->n_cus * (long)((160 * 1024) / per_wg);
+    }
     if (allow && e->K <= 10 && e->S <= 4) { e->ST = 4; e->SMX = 4; }
-    else if (allow && e->K <= 10 && e->fuse_nbr && (small_world || force || !table_fits)) { e->ST = 4; e->SMX = 16; }
+    else if (allow && e->K <= 10 && e->fuse_nbr && (small_world || force || !table_resident)) { e->ST = 4; e->SMX = 16; }
     else { e->ST = 0; e->SMX = 16; }
     e->lds = step_lds_bytes(e->BS, e->K, e->S, e->ST, e->KT);
     {   // helper lanes for the uniform-grid neighbour scan: arenas of 192 .. 512 agents on the register-line kernel
@@ -599,6 +629,24 @@ static hipError_t apply_variant_attributes(ca_env* e) {
         else r = set_lds_attr_k<16, 0>(e->BS, e->lds);
     }
     return r;
+}
+
+// Which form the ALAN online step takes on this handle (ca_alan_configure, and again whenever pick_variant has run: the world decides
+// the solve kernel).  One launch of the four-lanes kernel (alan_fused), one launch of a lane kernel of one or two waves (alan_lane:
+// the softmax terms wait in the wave's LP3 pool -- 4 + KMAX doubles per lane -- or, LDS line table, in the table itself -- 2 (K + S)
+// per lane), else select -> solve -> update.
+static int alan_pick(ca_env* e) {
+    e->alan_fused = e->alan_lane = false;
+    if (e->n_actions <= 0) return CA_OK;
+    const size_t lq = quad_lds_bytes(e->BSq, e->KT, e->SQ, e->n_actions);
+    const char* fv = getenv("CA_ALAN_FUSED");   // diagnostic switch: 0 = the three-launch form everywhere
+    const bool on = !(fv && fv[0] == '0');
+    e->alan_fused = on && (e->quad || e->quad_roll) && lq <= 64 * 1024;
+    e->alan_lane = on && !e->quad && e->fuse_nbr && !e->help && !e->pair && e->BS <= 128 && e->K <= 10 &&
+                   e->n_actions <= (e->ST > 0 ? 4 + e->KT : 2 * (e->K + e->S));
+    if (e->alan_fused && lq > 48 * 1024)
+        HIPCHK(e, hipFuncSetAttribute(quad_fn(e, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq));
+    return CA_OK;
 }
 
 extern "C" {
@@ -672,6 +720,10 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     }
     e->K = cfg->max_neighbors;
     e->S = cfg->max_obst_neighbors;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->n_cus = cus;
+    }
     pick_variant(e);
     {   // four lanes per agent (ca_quad.h) where one lane per agent would leave SIMDs without a wave: fewer than 1024
         // waves.  Measured crossover (profiles/r03_d_lane_vs_quad_by_batch_size.txt): 16-agent arenas -- quad ahead up to
@@ -858,7 +910,7 @@ static int install_tables(ca_env* e, std::vector<ObstDev>& all, std::vector<int>
     e->max_edges = me;
     pick_variant(e);
     HIPCHK(e, apply_variant_attributes(e));
-    return CA_OK;
+    return alan_pick(e);   // (the form of the ALAN step follows the solve kernel)
 }
 
 int ca_set_obstacles(ca_env* e, const float* verts_xy, const int32_t* poly_sizes, int32_t n_poly) {
@@ -1340,17 +1392,8 @@ int ca_alan_configure(ca_env* e, const double* actions_xy, int32_t n_actions, do
         memcpy(h.act_c, e->act_c, sizeof h.act_c); memcpy(h.act_s, e->act_s, sizeof h.act_s);
         h.temp = temp; h.window = timewindow; h.dt = time_step; h.reward_scale = e->cfg.reward_scale; h.nA = n_actions;
         HIPCHK(e, upload(e, e->d_alan, &h, sizeof h));
-        const size_t lq = quad_lds_bytes(e->BSq, e->KT, e->SQ, n_actions);
-        const char* fv = getenv("CA_ALAN_FUSED");   // diagnostic switch: 0 = the three-launch form everywhere
-        e->alan_fused = (e->quad || e->quad_roll) && lq <= 64 * 1024 && !(fv && fv[0] == '0');
-        // the lane kernels of one and two waves with register lines have an ALAN instantiation too: the softmax terms wait in
-        // the wave's LP3 pool, ML = 4 + KMAX doubles per lane
-        e->alan_lane = !e->quad && !(fv && fv[0] == '0') && e->fuse_nbr && e->ST > 0 && e->SMX == 4 && !e->help && !e->pair &&
-                       e->BS <= 128 && e->KT <= 10 && n_actions <= 4 + e->KT;
-        if (e->alan_fused && lq > 48 * 1024)
-            HIPCHK(e, hipFuncSetAttribute(quad_fn(e, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq));
     }
-    return CA_OK;
+    return alan_pick(e);
 }
 
 int ca_alan_step(ca_env* e, const double* u, int32_t u_is_device, uint32_t flags) {

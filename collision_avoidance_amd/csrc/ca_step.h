@@ -30,18 +30,19 @@ __host__ __device__ inline size_t step_lds_bytes(int BS, int K, int S, int ST = 
 typedef const __attribute__((address_space(4))) StepCold ColdK;  // the cold block through the constant address space
 
 // An agent with MORE obstacle neighbours than the register-line kernel has obstacle slots (ST): solved apart, by its own
-// lane alone, exactly as the contract says -- every half-plane built in order into one contiguous LDS table (the wave's LP3
-// pool is free at that point), LP2 over it; the caller runs LP3 on the same table with lp3_coop (stride 1) if LP2 fails.
+// lane alone, exactly as the contract says -- every half-plane built in order into an LDS table of its own (the wave's LP3
+// pool is free at that point: it holds TS such tables side by side, column g = table g, so up to TS such agents of a wave are
+// solved at the same time), LP2 over it; the caller runs LP3 on the same tables with lp3_coop (stride TS) where LP2 fails.
 // RVO2 keeps every edge in range (env.py:249, 301-318), so the list capacity stays 16; in the reference's doorway and
 // "congested" worlds (14 edges) no agent-step of 3.8e5 sampled had more than four (profiles/r04_b_reference_worlds.txt),
 // which is what lets those worlds run on the register-line kernel.  Not inlined: the hot path's registers are not its.
-template <bool NW16>
+template <bool NW16, int TS>
 __device__ __noinline__ void solve_many_obstacles(float4* tbl, int MLX, const ObstDev* tab, const unsigned short* oidx, const void* nidx,
                                                  int stride, int ocnt, int ncnt, const float* arena, int bs, V2 pos, V2 vel, V2 pref,
                                                  float R, float invTO, float invT, float invDt, float max_speed) {
     // (few enough arguments to travel in registers: one on the stack would give the whole kernel a scratch segment)
     const float *ax = arena, *ay = arena + bs, *avx = arena + 2 * bs, *avy = arena + 3 * bs;  // the staged arena: px | py | vx | vy
-    LdsLines ls; ls.base = tbl; ls.stride = 1;
+    LdsLines ls; ls.base = tbl; ls.stride = TS;
     int nl = 0;
     for (int s = 0; s < ocnt; ++s) {
         const int e = ld_idx_t<true>(oidx, (size_t)s * (size_t)stride);
@@ -64,7 +65,7 @@ __device__ __noinline__ void solve_many_obstacles(float4* tbl, int MLX, const Ob
     V2 nv = mk(0.0f, 0.0f);
     const int fail = lp2(ls, nl, max_speed, pref, false, nv);
     // lp3_coop's slot header; the caller reads the result (and whether LP3 is needed: fail < nl) from it
-    tbl[2 * MLX - 1] = make_float4(nv.x, nv.y, __int_as_float(nl | (numObst << 8) | (fail << 16)), 0.0f);
+    tbl[(2 * MLX - 1) * TS] = make_float4(nv.x, nv.y, __int_as_float(nl | (numObst << 8) | (fail << 16)), 0.0f);
 }
 
 #ifndef CA_LB512
@@ -73,7 +74,8 @@ __device__ __noinline__ void solve_many_obstacles(float4* tbl, int MLX, const Ob
 // HELP = 2: launched with 2 BS lanes, the upper half helps in the neighbour scan and ends (ca_nbr.h)
 // SMX: capacity of the obstacle-neighbour list (S <= SMX).  SMX > ST (register lines): the rare agent with more than ST
 // obstacle neighbours is solved apart (solve_many_obstacles)
-// ALAN (register-line kernels of one and two waves, K <= 10): the online bandit of ALAN_true.py:569-628 around the step, as in the
+// ALAN (kernels of one and two waves, K <= 10 -- register lines with obstacle lists of 4 or 16, and the LDS line table: every world
+// of the reference's ALAN runs, ALAN:738-772): the online bandit of ALAN_true.py:569-628 around the step, as in the
 // four-lanes kernel (ca_quad.h) -- softmax draw and rotated preferred velocity in the prologue (the softmax terms wait in the wave's
 // LP3 pool, which is free then: at most ML actions), reward and the sliding-window update of weights / times (global memory,
 // [A][nA][N]) where the epilogue begins; the goal direction is derived again there from the staged pre-step position instead of
@@ -135,12 +137,16 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
             typedef const __attribute__((address_space(4))) AlanCold AlanK;
             const AlanK& al = *(AlanK*)p.alan;
             const int nA = al.nA;
-            double* ps = reinterpret_cast<double*>(s_lines + (size_t)(tid >> 6) * (2 * ML) * POOL_SLOTS) + (tid & 63);   // [k][lane] in the wave's pool
+            // [k][lane] in the wave's LP3 pool (ML doubles per lane), or -- LDS line table -- over the table itself, which is
+            // empty until the barrier below (2 (K + S) doubles per lane); ca_alan_configure checks that the actions fit
+            constexpr int PSTR = ST > 0 ? 64 : BS;
+            double* ps = ST > 0 ? reinterpret_cast<double*>(s_lines + (size_t)(tid >> 6) * (2 * ML) * POOL_SLOTS) + (tid & 63)
+                                : reinterpret_cast<double*>(s_lines) + tid;
             const double* w = al.w + (size_t)a * nA * N + i;
-            for (int k = 0; k < nA; ++k) ps[k * 64] = exp64(w[(size_t)k * N] / al.temp);
-            const double sum = np_sum(nA, [&](int k) { return ps[k * 64]; });
+            for (int k = 0; k < nA; ++k) ps[k * PSTR] = exp64(w[(size_t)k * N] / al.temp);
+            const double sum = np_sum(nA, [&](int k) { return ps[k * PSTR]; });
             double acc = 0.0;
-            for (int k = 0; k < nA; ++k) { const double v = ps[k * 64] / sum; ps[k * 64] = v; acc += v; }
+            for (int k = 0; k < nA; ++k) { const double v = ps[k * PSTR] / sum; ps[k * PSTR] = v; acc += v; }
             double ui, u1;
             if (p.alan_u) ui = p.alan_u[q];
             else {
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
             double run = 0.0;
             bool found = false;
             for (int k = 0; k < nA - 1; ++k) {
-                run += ps[k * 64];
+                run += ps[k * PSTR];
                 if (!found && run / acc > ui) { act_id = k; found = true; }
             }
             double dgx, dgy;
@@ -298,11 +304,13 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
                     need = false;
                 }
             }
-            if constexpr (SMX > ST) {   // the agents with more than ST obstacle neighbours, one at a time (rare by selection)
+            if constexpr (SMX > ST) {   // the agents with more than ST obstacle neighbours, GX at a time (rare in small worlds; every
+                // sixth agent-step of the two-way tube, which takes this kernel when its batch is large: ca_env.hip pick_variant)
                 // (everything this stage needs is derived afresh from the lane id, the staged arena and the lists the lane
                 // wrote itself -- behind an opaque move, so that nothing of it lives in registers across the solve)
                 constexpr int MLX = SMX + KMAX;
-                static_assert(2 * MLX <= 2 * ML * POOL_SLOTS, "the single-agent table fits the wave's pool");
+                constexpr int GX = (2 * ML * POOL_SLOTS) / (2 * MLX);   // tables of 2 MLX rows side by side in the wave's pool
+                static_assert(GX >= 1 && GX <= POOL_SLOTS, "the many-obstacle tables fit the wave's pool");
                 int tid_o = threadIdx.x;
                 asm volatile("" : "+v"(tid_o));
                 int la_o, i_o;
@@ -310,26 +318,35 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
                 const int a_o = p.a0 + work_block(p) * apb + la_o;
                 const bool act_o = (a_o < p.a1) && (i_o < N) && (la_o < apb) && !arena_frozen(p, a_o);
                 const int cnts_o = act_o ? (int)p.counts[a_o * N + i_o] : 0;
-                unsigned long long om = __ballot((cnts_o >> 8) > ST);
-                while (om) {
-                    const int ln = __ffsll((long long)om) - 1;
-                    om &= om - 1ull;
-                    if ((tid_o & 63) == ln) {
+                bool need_o = (cnts_o >> 8) > ST;
+                const unsigned long long below_o = (1ull << (tid_o & 63)) - 1ull;
+                while (true) {
+                    const unsigned long long om = __ballot(need_o);
+                    if (!om) break;
+                    const int rank = __popcll(om & below_o);
+                    const bool mine = need_o && rank < GX;
+                    if (mine) {
                         const ObstDev* tab_o = p.obst + (p.tab_off != nullptr ? p.tab_off[a_o] : 0);
-                        solve_many_obstacles<CA_NBW16(BS)>(pool, MLX, tab_o, obst_idx_s + (size_t)a_o * S * N + i_o,
-                                                           (const char*)nb_idx_s + ((size_t)a_o * K * N + i_o) * (CA_NBW16(BS) ? 2 : 1), N,
-                                                           cnts_o >> 8, cnts_o & 0xFF, s_px + (tid_o - i_o), BS,
-                                                           mk(s_px[tid_o], s_py[tid_o]), mk(s_vx[tid_o], s_vy[tid_o]), opt_fn(), p.radius,
-                                                           1.0f / p.time_horizon_obst, 1.0f / p.time_horizon, 1.0f / p.time_step, p.max_speed);
+                        solve_many_obstacles<CA_NBW16(BS), GX>(pool + rank, MLX, tab_o, obst_idx_s + (size_t)a_o * S * N + i_o,
+                                                               (const char*)nb_idx_s + ((size_t)a_o * K * N + i_o) * (CA_NBW16(BS) ? 2 : 1), N,
+                                                               cnts_o >> 8, cnts_o & 0xFF, s_px + (tid_o - i_o), BS,
+                                                               mk(s_px[tid_o], s_py[tid_o]), mk(s_vx[tid_o], s_vy[tid_o]), opt_fn(), p.radius,
+                                                               1.0f / p.time_horizon_obst, 1.0f / p.time_horizon, 1.0f / p.time_step, p.max_speed);
                     }
                     wave_lds_sync();
-                    const int hz = __float_as_int(pool[2 * MLX - 1].z);   // n | numObst << 8 | fail << 16 (wave-uniform read)
-                    if (((hz >> 16) & 0xFF) < (hz & 0xFF)) {               // LP2 failed: LP3 on the same table, four lanes
-                        lp3_coop(pool, MLX, 1, p.max_speed, 1);
+                    const int waiting = __popcll(om);
+                    const int nt = waiting < GX ? waiting : GX;    // tables of this round
+                    bool lp3 = false;
+                    if ((tid_o & 63) < nt) {
+                        const int hz = __float_as_int(pool[(2 * MLX - 1) * GX + (tid_o & 63)].z);   // n | numObst << 8 | fail << 16
+                        lp3 = ((hz >> 16) & 0xFF) < (hz & 0xFF);
+                    }
+                    if (__ballot(lp3) != 0ull) {   // LP2 failed somewhere: LP3 on the same tables, four lanes each (a table whose LP2
+                        lp3_coop(pool, MLX, nt, p.max_speed, GX);   // succeeded has begin = n: untouched)
                         wave_lds_sync();
                     }
-                    if ((tid_o & 63) == ln) { const float4 h = pool[2 * MLX - 1]; nv = mk(h.x, h.y); }
-                    wave_lds_sync();   // (the next such agent rewrites the table)
+                    if (mine) { const float4 h = pool[(2 * MLX - 1) * GX + rank]; nv = mk(h.x, h.y); need_o = false; }
+                    wave_lds_sync();   // (the next round rewrites the tables)
                 }
             }
         }

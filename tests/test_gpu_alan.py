@@ -295,16 +295,24 @@ def test_fused_alan_launch_equals_three_launch_form_and_oracle():
     fused.close(); plain.close()
 
 
-@pytest.mark.parametrize("scenario,A,N,acts,over", [
-    ("crowd", 30, 16, alan.DEFAULT_ACTIONS, {}),                       # one wave, K = 10, 8 actions
-    ("circle", 5, 100, ACTS9, {}),                                     # two waves per arena, 9 actions
-    ("crowd", 9, 40, alan.DEFAULT_ACTIONS[:3], dict(max_neighbors=5, neighbor_dist=2.0)),   # the K = 5 kernel
-    ("crowd", 6, 24, [(1, 0), (0, 1)] * 16, {}),                       # 32 actions: more than the pool holds -> three launches
+@pytest.mark.parametrize("scenario,A,N,acts,over,one_launch", [
+    ("crowd", 30, 16, alan.DEFAULT_ACTIONS, {}, True),                 # one wave, K = 10, 8 actions
+    ("circle", 5, 100, ACTS9, {}, True),                               # two waves per arena, 9 actions
+    ("crowd", 9, 40, alan.DEFAULT_ACTIONS[:3], dict(max_neighbors=5, neighbor_dist=2.0), True),   # the K = 5 kernel
+    ("crowd", 6, 24, [(1, 0), (0, 1)] * 16, {}, False),                # 32 actions: more than the pool holds -> three launches
+    # the worlds of the reference's own ALAN runs (ALAN:738-772) that have obstacles:
+    ("congested", 7, 50, ACTS9, {}, True),                             # register lines, obstacle lists of 16 (a world of <= 16 edges)
+    ("congested", 3, 100, ACTS9, {}, True),                            # ... two waves per arena
+    ("deadlock", 7, 50, ACTS9[:2], {}, True),                          # the LDS line table (42 edges), softmax terms in the table
+    ("deadlock", 3, 100, ACTS9, {}, True),                             # ... two waves per arena (57 KB of LDS)
+    ("blocks", 9, 20, alan.DEFAULT_ACTIONS, {}, True),                 # a world per arena
+    ("deadlock", 4, 40, [(1, 0), (0, 1)] * 16, {}, True),              # 32 actions fit the table (2 (K + S) = 52 per lane)
 ])
-def test_alan_inside_the_lane_kernel(scenario, A, N, acts, over):
-    """Batches on the one-lane-per-agent register-line kernels (forced here with CA_QUAD=0; by default every batch of 1024 or
+def test_alan_inside_the_lane_kernel(scenario, A, N, acts, over, one_launch):
+    """Batches on the one-lane-per-agent kernels (forced here with CA_QUAD=0; by default every batch of 1024 or
     more waves) run the bandit inside the solve launch too (csrc/ca_step.h, ALAN instantiation): against the oracle, bit for
-    bit, with caller-supplied uniforms, the handle's own draws, statistics, observation and per-arena freezing."""
+    bit, with caller-supplied uniforms, the handle's own draws, statistics, observation and per-arena freezing.  The
+    profile shows the form taken: no launch of the small select / update kernels when the bandit is inside the solve."""
     import os
     p = H.scenario_params(scenario, N, max_step=70, **over)
     os.environ["CA_QUAD"] = "0"
@@ -316,9 +324,12 @@ def test_alan_inside_the_lane_kernel(scenario, A, N, acts, over):
     g.alan_configure(acts); e.alan_configure(acts)
     assert g.launch_info()["lanes_per_agent"] == 1
     rng = np.random.RandomState(9)
+    g.profile(1); g.profile_read()
     for s in range(8):
         u = rng.uniform(0, 1, (A, N))
         g.alan_step(u=u, stats=True); e.alan_step(u=u, flags=o.F_STATS)
+    prof = g.profile_read(); g.profile(0)
+    assert prof["step_kernel"][0] == 8 and prof["reset_kernels"][0] == (0 if one_launch else 16), prof
     _assert_alan_equal(g, e, "given uniforms")
     sc = (np.arange(A) % 17).astype(np.int32) + g.get(_lib.FLD_STEP_COUNT)     # the arenas end at different steps
     g.set(_lib.FLD_STEP_COUNT, sc); e.set(o.FLD_STEP_COUNT, sc)

@@ -5,9 +5,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from collision_avoidance_amd import scenarios, alan
 from collision_avoidance_amd.vec_env import VecCollisionAvoidanceEnv
-for scen, A, N in (("crowd", 1024, 16), ("crowd", 1024, 50), ("circle", 1024, 100), ("crowd", 4096, 64)):
+SHAPES = (("crowd", 1024, 16), ("crowd", 1024, 50), ("circle", 1024, 100), ("crowd", 4096, 64))
+if len(sys.argv) > 1 and sys.argv[1] == "worlds":   # the reference's ALAN runs that have obstacles (ALAN:738-772), as batches of lane-kernel size
+    SHAPES = (("congested", 4096, 50), ("deadlock", 4096, 50), ("blocks", 8192, 20))
+for scen, A, N in SHAPES:
     p = scenarios.alan_params(N, scen)
-    p.update(done_mode=scenarios.DONE_REGOAL, max_step=0)
+    if scen in ("crowd", "circle"):
+        p.update(done_mode=scenarios.DONE_REGOAL, max_step=0)
+    else:
+        p.update(max_step=0)   # (goal -> second goal, no episode end: the agents keep walking between their two targets)
     env = VecCollisionAvoidanceEnv(A, N, scenario=scen, params=p, use_torch=False)
     env.alan_configure(alan.DEFAULT_ACTIONS)
     env.alan_rollout(1000, stats=True, freeze=False); env.sync()
