@@ -137,3 +137,8 @@ def test_no_hot_kernel_uses_scratch_memory():
     # is not among the exemptions: no scratch at all
     own = [r for r in rows if r["name"].startswith("step_kernel<5, 64, 4, true, 1, 16, false>")]
     assert own and own[0]["scratch"] == 0 and own[0]["vgpr_spill"] == 0, own
+    # ... nor are the kernels that large batches of the reference's ALAN worlds select (congested, deadlock, blocks: K = 10, up to
+    # 64 agents, ALAN:195-208, 359-372, 418-455), with and without the bandit inside the launch
+    for want in ("step_kernel<10, 64, 4, true, 1, 16, false>", "step_kernel<10, 64, 4, true, 1, 16, true>"):
+        k = [r for r in rows if r["name"].startswith(want)]
+        assert k and k[0]["scratch"] == 0 and k[0]["vgpr_spill"] == 0, (want, k)

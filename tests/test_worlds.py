@@ -297,3 +297,42 @@ def test_large_arena_with_sixteen_obstacle_neighbours_is_accepted():
     H.assert_state_equal(g, e, "300 agents behind the doorway", obs=True)
     H.assert_stats_equal(g, e, "300 agents behind the doorway")
     g.close()
+
+
+@pytest.mark.gpu
+def test_large_batches_of_many_edge_worlds_take_the_register_lines():
+    """The two-way tube of the ALAN runs ("deadlock", 42 edges + cuts, ALAN:418-455; every sixth agent-step has more than four
+    edges in range): a batch the chip holds at once with the LDS line table keeps the table, a larger one takes the register
+    lines with the many-obstacles stage (ca_env.hip pick_variant: five 64-lane table workgroups fit a CU) -- same bits either
+    way: full steps with observation, then ALAN online steps inside the same launch, every arena against the oracle."""
+    from collision_avoidance_amd import _lib, alan
+    N = 50
+    p = H.scenario_params("deadlock", N, max_step=400)
+    small = H.make_gpu(1100, N, "deadlock", p, seed=3)       # (fewer than 1024 waves would take the four-lanes kernel)
+    assert small.launch_info()["lanes_per_agent"] == 1
+    assert small.launch_info()["lds_bytes"] == 64 * ((10 + 16) * 16 + 32)          # the line table: [K + S][lanes] float4 + staging
+    small.close()
+    A = 1536
+    g = H.make_gpu(A, N, "deadlock", p, seed=3)
+    e = H.make_oracle(A, N, "deadlock", p, seed=3)
+    assert g.launch_info()["lanes_per_agent"] == 1 and g.launch_info()["lds_bytes"] == 2 * 14 * 16 * 16 + 64 * 32   # the wave's LP3 pool + staging
+    rng = np.random.RandomState(4)
+    many = 0
+    for s in range(24):
+        act = rng.uniform(-1.0, 1.0, (A, N)).astype(np.float32)
+        g.step(act, stats=True)
+        e.step_mt(act, flags=o.F_OBS | o.F_STATS, n_threads=8)
+        many += int((e.get(o.FLD_OBST_COUNT) > 4).sum())
+    H.assert_state_equal(g, e, "tube, full steps", obs=True, reward=True)
+    assert many > 0.05 * 24 * A * N, many
+    g.alan_configure(alan.DEFAULT_ACTIONS); e.alan_configure(alan.DEFAULT_ACTIONS)
+    g.profile(1); g.profile_read()
+    for s in range(6):
+        g.alan_step(stats=True); e.alan_step(flags=o.F_STATS)
+    prof = g.profile_read(); g.profile(0)
+    assert prof["step_kernel"][0] == 6 and prof["reset_kernels"][0] == 0, prof     # the bandit ran inside the solve launch
+    H.assert_state_equal(g, e, "tube, ALAN steps")
+    assert np.array_equal(g.get(_lib.FLD_ALAN_WEIGHTS).view(np.uint64), e.get(o.FLD_ALAN_WEIGHTS).view(np.uint64)), "ALAN weights"
+    H.assert_stats_equal(g, e, "tube")
+    assert g.stats()["obst_overflow"] == 0
+    g.close()
