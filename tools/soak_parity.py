@@ -25,10 +25,14 @@ cases = [("crowd", 64, scenarios.bench_params(64, 5.0, 10), 11), ("crowd", 64, s
          # round 4: the two-lanes kernel (arenas of 129 .. 512 agents: grid order, scan bounded by the previous list), the
          # register-line kernel with obstacle lists of 16 (K = 10 world of 14 edges), a mid-size arena on the lane kernel
          ("crowd", 512, scenarios.bench_params(512, 5.0, 10), 19), ("crowd", 180, scenarios.bench_params(180, 5.0, 10), 21),
-         ("congested", 24, H.scenario_params("congested", 24), 23), ("crowd", 100, scenarios.bench_params(100, 5.0, 10), 25)]
-for scen, N, p, seed in cases:
+         ("congested", 24, H.scenario_params("congested", 24), 23), ("crowd", 100, scenarios.bench_params(100, 5.0, 10), 25),
+         # round 4, second session: many-edge worlds in batches that are NOT resident with the LDS line table take the register lines,
+         # their many-obstacle agents solved apart eight at a time (from 1281 workgroups: the tube at 50 agents per arena, blocks at
+         # three 20-agent arenas per wave -- twice the arenas for that one)
+         ("deadlock", 50, H.scenario_params("deadlock", 50), 27), ("blocks", 20, H.scenario_params("blocks", 20), 29, 2)]
+for scen, N, p, seed, *mult in cases:
     t0 = time.time()
-    A_case = A if N <= 64 else max(8, A // 16 if N <= 256 else A // 64)
+    A_case = (A if N <= 64 else max(8, A // 16 if N <= 256 else A // 64)) * (mult[0] if mult else 1)
     g = H.make_gpu(A_case, N, scen, p, seed=seed)
     e = H.make_oracle(A_case, N, scen, p, seed=seed)
     rng = np.random.RandomState(seed)
