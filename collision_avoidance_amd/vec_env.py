@@ -119,14 +119,37 @@ class VecCollisionAvoidanceEnv:
             return (self.A, self.n_actions, self.N), dt      # device layout; get()/set() present [A, N, n_actions]
         return (self.A, self.N), dt
 
-    def get(self, field):
-        """Host copy of a state field (synchronises the stream)."""
+    def get(self, field, out=None):
+        """Host copy of a state field (synchronises the stream).  out: a C-contiguous array of the field's device shape and
+        dtype to fill instead of a new one (e.g. host_buffer(field): page-locked, so the copy runs at the link's rate)."""
         shape, dt = self._shape_dtype(field)
-        out = np.empty(shape, dt)
+        if out is None:
+            out = np.empty(shape, dt)
+        elif out.shape != tuple(shape) or out.dtype != np.dtype(dt) or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("get: out must be a C-contiguous %s array of shape %s" % (np.dtype(dt).name, tuple(shape)))
         self._call("ca_get", self.h, field, _ptr(out), out.nbytes, 0)
         if field in (_lib.FLD_ALAN_WEIGHTS, _lib.FLD_ALAN_TIMES):
             return np.ascontiguousarray(np.transpose(out, (0, 2, 1)))   # [A, N, n_actions] like ALAN_true.py:75-76
         return out
+
+    def host_buffer(self, field):
+        """A persistent host array for a field, page-locked when PyTorch can allocate pinned memory (a pageable destination
+        takes the 67-MB observation of 4096 x 64 agents at ~10 GB/s, a pinned one at the PCIe rate).  Owned by the
+        environment and reused by step(copy=False): valid until the next call that writes it -- the reference's own
+        ownership rule (env.py:463-466: the same dict objects every call, mutated in place)."""
+        bufs = self.__dict__.setdefault("_host_bufs", {})
+        if field not in bufs:
+            shape, dt = self._shape_dtype(field)
+            arr = None
+            if torch is not None and torch.cuda.is_available():
+                try:
+                    t = torch.empty(tuple(shape), dtype=getattr(torch, np.dtype(dt).name), pin_memory=True)
+                    arr = t.numpy()
+                    self.__dict__.setdefault("_host_pins", []).append(t)    # keeps the pinned storage alive
+                except Exception:
+                    arr = None
+            bufs[field] = np.empty(shape, dt) if arr is None else arr
+        return bufs[field]
 
     def set(self, field, arr):
         shape, dt = self._shape_dtype(field)
@@ -284,9 +307,11 @@ class VecCollisionAvoidanceEnv:
                     last_episode_steps=(r[:, 7] >> np.uint64(32)).astype(np.int64),
                     last_episode_arrived=(r[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.int64))
 
-    def step(self, actions, with_obs=True, stats=False, autoreset=False):
+    def step(self, actions, with_obs=True, stats=False, autoreset=False, copy=True):
         """reference step(action) (env.py:367-416) for every arena.
-        actions [A,N] heading offsets (rad).  Returns (obs [A,N,64], rewards [A,N], dones [A], {})."""
+        actions [A,N] heading offsets (rad).  Returns (obs [A,N,64], rewards [A,N], dones [A], {}).
+        copy=False (numpy mode): the results land in the environment's own page-locked host buffers (host_buffer) and are
+        valid until the next step / reset -- no allocation per step and the device -> host copy at the link's rate."""
         flags = (_lib.F_OBS if with_obs else 0) | (_lib.F_STATS if stats else 0) | \
                 (_lib.F_AUTORESET if autoreset else 0)
         if self.use_torch:
@@ -302,6 +327,10 @@ class VecCollisionAvoidanceEnv:
             return (self._obs_t if with_obs else None), self._rew_t, self._done_t, {}
         a = np.ascontiguousarray(np.asarray(actions, np.float32).reshape(self.A, self.N))
         self._call("ca_step_host", self.h, _ptr(a), flags)
+        if not copy:
+            return (self.get(_lib.FLD_OBS, self.host_buffer(_lib.FLD_OBS)) if with_obs else None), \
+                self.get(_lib.FLD_REWARD, self.host_buffer(_lib.FLD_REWARD)), \
+                self.get(_lib.FLD_ARENA_DONE, self.host_buffer(_lib.FLD_ARENA_DONE)), {}
         return (self.get(_lib.FLD_OBS) if with_obs else None), self.get(_lib.FLD_REWARD), \
             self.get(_lib.FLD_ARENA_DONE), {}
 

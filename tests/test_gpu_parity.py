@@ -603,3 +603,26 @@ def test_zero_copy_field_views():
     np.testing.assert_array_equal(g.cpu().numpy(), env.get(_lib.FLD_GOAL_X))
     assert obs.data_ptr() == env.field_tensor(_lib.FLD_OBS).data_ptr()      # the bound observation tensor
     env.close()
+
+
+def test_host_results_in_the_environments_own_buffers():
+    """numpy mode, step(copy=False): observation, reward and done flags land in the environment's own (page-locked) host
+    buffers -- the same arrays every call, mutated in place, as the reference hands its dicts out (env.py:463-466) -- and hold
+    what fresh copies hold; get(out=...) refuses a buffer of the wrong shape."""
+    from collision_avoidance_amd import _lib
+    env = H.make_gpu(12, 16, "crowd", scenarios.bench_params(16, 1.5, 5), use_torch=False)
+    env.reset()
+    rng = np.random.RandomState(3)
+    first = None
+    for s in range(6):
+        obs, rew, done, _ = env.step(rng.uniform(-0.5, 0.5, (12, 16)).astype(np.float32), copy=False)
+        if first is None:
+            first = (obs, rew, done)
+        assert obs is first[0] and rew is first[1] and done is first[2]
+        np.testing.assert_array_equal(obs, env.get(_lib.FLD_OBS))
+        np.testing.assert_array_equal(rew, env.get(_lib.FLD_REWARD))
+        np.testing.assert_array_equal(done, env.get(_lib.FLD_ARENA_DONE))
+    assert obs.shape == (12, 16, 64) and obs.dtype == np.float32 and np.abs(obs).max() > 0
+    with pytest.raises(ValueError):
+        env.get(_lib.FLD_OBS, out=np.empty((12, 16), np.float32))
+    env.close()

@@ -14,16 +14,19 @@ env = VecCollisionAvoidanceEnv(A, N, "crowd", scenarios.bench_params(N, w["neigh
 rng = np.random.RandomState(0)
 pool = [rng.uniform(-0.5, 0.5, (A, N)).astype(np.float32) for _ in range(4)]
 env.rollout(2000, stats=True)     # settle the crowd
-for mode in ("host actions in, observation / reward / done out", "host actions in, nothing copied back"):
-    out = mode.endswith("done out")
+for mode in ("host actions in, observation / reward / done out (new pageable arrays)",
+             "host actions in, observation / reward / done out (the environment's page-locked buffers, copy=False)",
+             "host actions in, nothing copied back"):
+    out = "done out" in mode
+    pinned = "copy=False" in mode
     for i in range(5):
-        env.step(pool[i % 4], with_obs=True, stats=True) if out else env._call("ca_step_host", env.h, pool[i % 4].ctypes.data, 3)
+        env.step(pool[i % 4], with_obs=True, stats=True, copy=not pinned) if out else env._call("ca_step_host", env.h, pool[i % 4].ctypes.data, 3)
     env.sync()
     n = 100
     t0 = time.perf_counter()
     for i in range(n):
         if out:
-            env.step(pool[i % 4], with_obs=True, stats=True)
+            env.step(pool[i % 4], with_obs=True, stats=True, copy=not pinned)
         else:
             env._call("ca_step_host", env.h, pool[i % 4].ctypes.data, 3)   # CA_F_OBS | CA_F_STATS
     env.sync()
