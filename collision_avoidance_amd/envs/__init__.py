@@ -63,6 +63,7 @@ class Collision_Avoidance_Env(*_bases):
         self.observation_space = box(low=-self.neighborDist, high=self.neighborDist,
                                      shape=(self.laser_num * 4,))                               # env.py:53
         self._device, self._seed = device, seed
+        self._keys = ['agent_' + str(i) for i in range(numAgents)]                              # env.py:275, 373, 400
         self._make()
         self.reset()                                                                            # env.py:74
 
@@ -79,8 +80,9 @@ class Collision_Avoidance_Env(*_bases):
         return [int(v) for v in self.vec.get(_lib.FLD_AGENT_DONE)[0]]
 
     def _fill_obs(self, obs):
-        for i in range(self.numAgents):
-            self.gym_obs['agent_' + str(i)] = [float(v) for v in obs[0, i]]
+        rows = obs[0].tolist()      # 64 Python floats per agent, as the reference's lists (env.py:275)
+        for k, row in zip(self._keys, rows):
+            self.gym_obs[k] = row
         return self.gym_obs
 
     def reset(self):
@@ -94,11 +96,10 @@ class Collision_Avoidance_Env(*_bases):
 
     def step(self, action):
         # env.py:367-416.  A missing agent key raises KeyError like the reference (env.py:373).
-        act = np.array([float(np.asarray(action['agent_' + str(i)]).reshape(-1)[0])
-                        for i in range(self.numAgents)], np.float32)
+        act = np.array([float(np.asarray(action[k]).reshape(-1)[0]) for k in self._keys], np.float32)
         obs, rew, done, _ = self.vec.step(act.reshape(1, -1))
-        for i in range(self.numAgents):
-            self.gym_rewards['agent_' + str(i)] = float(rew[0, i])
+        for k, r in zip(self._keys, rew[0].tolist()):
+            self.gym_rewards[k] = r
         self.gym_dones['__all__'] = bool(done[0])
         self._fill_obs(obs)
         return self.gym_obs, self.gym_rewards, self.gym_dones, self.gym_infos
