@@ -336,3 +336,42 @@ def test_large_batches_of_many_edge_worlds_take_the_register_lines():
     H.assert_stats_equal(g, e, "tube")
     assert g.stats()["obst_overflow"] == 0
     g.close()
+
+
+QUOTED = [  # the batches of the reference's own worlds whose rates DESIGN.md / BASELINE.md quote
+    ("doorway", 16384, 10),      # the drop-in env's configuration (env.py:26-123): register lines, dense packing, dense observation
+    ("congested", 4096, 50),     # ALAN:195-208: register lines, obstacle lists of 16
+    ("deadlock", 4096, 50),      # ALAN:418-455: the same kernel by the residency rule, many-obstacle agents eight at a time
+    ("blocks", 8192, 20),        # ALAN:359-372: a world per arena
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scenario,A,N", QUOTED, ids=[c[0] for c in QUOTED])
+def test_reference_world_batches_at_the_quoted_sizes(scenario, A, N):
+    """Every arena of the quoted batch shapes against the oracle, bit for bit: an ORCA-only rollout, then full steps with
+    actions, reward and the observation, then ALAN online steps (the oracle steps the batch on a thread pool)."""
+    import os
+    from collision_avoidance_amd import _lib, alan
+    nt = min(16, os.cpu_count() or 1)
+    p = H.scenario_params(scenario, N)
+    g = H.make_gpu(A, N, scenario, p, seed=6)
+    e = H.make_oracle(A, N, scenario, p, seed=6)
+    assert g.launch_info()["lanes_per_agent"] == 1 and g.launch_info()["lds_bytes"] < 16 * 1024     # a register-line kernel
+    g.rollout(12, stats=True)
+    e.rollout(12, flags=o.F_STATS, n_threads=nt)
+    H.assert_state_equal(g, e, scenario + " batch, ORCA rollout")
+    rng = np.random.RandomState(8)
+    for s in range(3):
+        act = rng.uniform(-1.0, 1.0, (A, N)).astype(np.float32)
+        g.step(act, stats=True)
+        e.step_mt(act, flags=o.F_OBS | o.F_STATS, n_threads=nt)
+    H.assert_state_equal(g, e, scenario + " batch, full steps", obs=True, reward=True)
+    if scenario != "doorway":   # (the env's own world has no ALAN run)
+        g.alan_configure(alan.DEFAULT_ACTIONS); e.alan_configure(alan.DEFAULT_ACTIONS)
+        for s in range(3):
+            g.alan_step(stats=True); e.alan_step(flags=o.F_STATS)
+        H.assert_state_equal(g, e, scenario + " batch, ALAN steps")
+    H.assert_stats_equal(g, e, scenario + " batch")
+    assert g.stats()["obst_overflow"] == 0
+    g.close()
