@@ -13,7 +13,7 @@ for scen, A, N in SHAPES:
     if scen in ("crowd", "circle"):
         p.update(done_mode=scenarios.DONE_REGOAL, max_step=0)
     else:
-        p.update(max_step=0)   # (goal -> second goal, no episode end: the agents keep walking between their two targets)
+        p.update(max_step=0)   # (no episode end: an agent that reaches its goal goes on to its second target and stays there, ALAN:553-562)
     env = VecCollisionAvoidanceEnv(A, N, scenario=scen, params=p, use_torch=False)
     env.alan_configure(alan.DEFAULT_ACTIONS)
     env.alan_rollout(1000, stats=True, freeze=False); env.sync()
