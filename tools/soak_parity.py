@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: long GPU-vs-oracle parity soak (bit-exact state, lists, observation, reward, counters) on larger
-batches than the unit tests use.  Usage (GPU box): python tools/soak_parity.py [arenas] [steps]"""
+batches than the unit tests use.  Usage (GPU box): python tools/soak_parity.py [arenas] [steps] [seed offset]"""
 import os
 import sys
 import time
@@ -15,6 +15,7 @@ from tests import helpers as H
 
 A = int(sys.argv[1]) if len(sys.argv) > 1 else 192
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+seed_offset = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # other scenario draws and actions: an independent run
 threads = max(1, min(32, len(os.sched_getaffinity(0))))
 cases = [("crowd", 64, scenarios.bench_params(64, 5.0, 10), 11), ("crowd", 64, scenarios.bench_params(64, 5.0, 10), 12),
          ("circle", 64, H.scenario_params("circle", 64), 3), ("doorway", 10, H.scenario_params("doorway", 10), 5),
@@ -31,6 +32,7 @@ cases = [("crowd", 64, scenarios.bench_params(64, 5.0, 10), 11), ("crowd", 64, s
          # three 20-agent arenas per wave -- twice the arenas for that one)
          ("deadlock", 50, H.scenario_params("deadlock", 50), 27), ("blocks", 20, H.scenario_params("blocks", 20), 29, 2)]
 for scen, N, p, seed, *mult in cases:
+    seed += seed_offset
     t0 = time.time()
     A_case = (A if N <= 64 else max(8, A // 16 if N <= 256 else A // 64)) * (mult[0] if mult else 1)
     g = H.make_gpu(A_case, N, scen, p, seed=seed)
