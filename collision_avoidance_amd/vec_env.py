@@ -158,6 +158,37 @@ class VecCollisionAvoidanceEnv:
         a = np.ascontiguousarray(np.asarray(arr, dt).reshape(shape))
         self._call("ca_set", self.h, field, _ptr(a), a.nbytes, 0)
 
+    # ---- checkpoint / resume -------------------------------------------------------------------------
+    _STATE_FIELDS = ("POS_X", "POS_Y", "VEL_X", "VEL_Y", "PREF_X", "PREF_Y", "GOAL_X", "GOAL_Y", "GOAL2_X", "GOAL2_Y",
+                     "AGENT_DONE", "ARRIVE_STEP", "NB_COUNT", "NB_IDX", "OBST_COUNT", "OBST_IDX", "STEP_COUNT", "ARENA_DONE",
+                     "EPISODE", "REGOAL_COUNT")
+
+    def get_state(self):
+        """Everything the next step depends on, as a dict of host arrays: simulator state, targets, the neighbour lists of
+        the last doStep (the observation of a reset reads them, env.py:461-488), the counters that key the random draws
+        (episode, re-goal count, step count) and, after alan_configure, the bandit's weights and times.  The reference never
+        serialises its environment (checkpoints exist at the trainer's level only); with counter-based
+        draws a restored environment continues bit for bit.  Statistics counters are not part of the state."""
+        st = {name: self.get(getattr(_lib, "FLD_" + name)) for name in self._STATE_FIELDS}
+        if self.n_actions > 0:
+            st["ALAN_WEIGHTS"] = self.get(_lib.FLD_ALAN_WEIGHTS)
+            st["ALAN_TIMES"] = self.get(_lib.FLD_ALAN_TIMES)
+        st["_shape"] = np.array([self.A, self.N, self.K, self.S, self.n_actions], np.int64)
+        return st
+
+    def set_state(self, st):
+        """Restore a get_state() dict into an environment of the same shape and configuration (seed included: it keys the
+        draws); the obstacle tables and the ALAN action set are configuration, not state."""
+        shape = [int(v) for v in np.asarray(st["_shape"]).reshape(-1)]
+        if shape != [self.A, self.N, self.K, self.S, self.n_actions]:
+            raise ValueError("set_state: the state is of an environment of shape %s, this one is %s"
+                             % (shape, [self.A, self.N, self.K, self.S, self.n_actions]))
+        for name in self._STATE_FIELDS:
+            self.set(getattr(_lib, "FLD_" + name), st[name])
+        if self.n_actions > 0:
+            self.set(_lib.FLD_ALAN_WEIGHTS, st["ALAN_WEIGHTS"])
+            self.set(_lib.FLD_ALAN_TIMES, st["ALAN_TIMES"])
+
     def field_tensor(self, field):
         """Zero-copy torch view of a state field's device buffer (valid until close(); kernels of this handle run on
         torch's current stream, so ordinary stream ordering applies)."""

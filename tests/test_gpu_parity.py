@@ -626,3 +626,52 @@ def test_host_results_in_the_environments_own_buffers():
     with pytest.raises(ValueError):
         env.get(_lib.FLD_OBS, out=np.empty((12, 16), np.float32))
     env.close()
+
+
+@pytest.mark.parametrize("with_alan", [False, True], ids=["env", "alan"])
+def test_checkpoint_and_resume_continue_bit_for_bit(with_alan, tmp_path):
+    """get_state() / set_state(): an environment restored from a snapshot (through a file) continues exactly like the one
+    that was never stopped -- state, lists, observation, reward, and the draws of re-goals, auto-resets and the ALAN bandit
+    (counter-based, keyed by the restored counters).  The reference never serialises its env."""
+    from collision_avoidance_amd import _lib, alan
+    A, N = 40, 24
+    p = scenarios.bench_params(N, 3.0, 10)
+    p.update(max_step=17)                       # episodes end inside the run: auto-reset draws new starts
+    if with_alan:
+        p = H.scenario_params("crowd", N, max_step=60)
+    a = H.make_gpu(A, N, "crowd", p, seed=9)
+    if with_alan:
+        a.alan_configure(alan.DEFAULT_ACTIONS)
+    rng = np.random.RandomState(1)
+    acts = rng.uniform(-0.7, 0.7, (45, A, N)).astype(np.float32)
+
+    def advance(env, lo, hi):
+        for s in range(lo, hi):
+            if with_alan:
+                env.alan_step(stats=True, freeze=True, with_obs=True)
+            else:
+                env.step(acts[s], stats=True, autoreset=True)
+    advance(a, 0, 25)
+    st = a.get_state()
+    np.savez(tmp_path / "ckpt.npz", **st)
+    advance(a, 25, 45)
+    b = H.make_gpu(A, N, "crowd", p, seed=9)    # a fresh handle: its own scenario draws are overwritten by the snapshot
+    if with_alan:
+        b.alan_configure(alan.DEFAULT_ACTIONS)
+    with np.load(tmp_path / "ckpt.npz") as z:
+        b.set_state({k: z[k] for k in z.files})
+    advance(b, 25, 45)
+    fields = [getattr(_lib, "FLD_" + n) for n in a._STATE_FIELDS] + [_lib.FLD_OBS, _lib.FLD_REWARD]
+    if with_alan:
+        fields += [_lib.FLD_ALAN_WEIGHTS, _lib.FLD_ALAN_TIMES, _lib.FLD_ALAN_ACTION]
+    for f in fields:
+        x, y = a.get(f), b.get(f)
+        if f in (_lib.FLD_NB_IDX, _lib.FLD_OBST_IDX):    # entries beyond the count are unspecified
+            cnt = a.get(_lib.FLD_NB_COUNT if f == _lib.FLD_NB_IDX else _lib.FLD_OBST_COUNT)
+            m = np.arange(x.shape[1])[None, :, None] < cnt[:, None, :]
+            x, y = np.where(m, x, -1), np.where(m, y, -1)
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), "field %d differs after the resume" % f
+    assert a.get(_lib.FLD_EPISODE).max() > 0 or with_alan           # the run really crossed episode ends
+    with pytest.raises(ValueError):
+        H.make_gpu(A + 1, N, "crowd", p, seed=9).set_state(st)
+    a.close(); b.close()
