@@ -179,6 +179,7 @@ __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
     __shared__ unsigned short s_sorted[BS];
     __shared__ float2 s_sxy[BS];
     __shared__ int s_red[4];   // per-arena reductions of the epilogue
+    __shared__ unsigned s_vmax2;   // the largest squared speed of the arena in this step, as float bits (the pair count's motion bound)
     const int tid = threadIdx.x;
     const int h = tid & 1, sl = tid >> 1;   // lane of the pair, agent slot of the pair
     const int a = p.a0 + (int)blockIdx.x;
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
         if (tid < 2) s_box[tid] = 0xFFFFFFFFu;
         if (tid >= 2 && tid < 4) s_box[tid] = 0u;
         if (tid >= 4 && tid < 8) s_red[tid - 4] = 0;
+        if (tid == 8) s_vmax2 = 0u;
         for (int cidx = tid; cidx < GMAX * GMAX; cidx += 2 * BS) s_ccnt[cidx] = 0;
         __syncthreads();
         CA_PSTAMP(1);
@@ -511,6 +513,10 @@ __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
     const ColdP& c = *(ColdP*)p.cold;
     pf32 = mk(reinterpret_cast<float*>(s_misc)[i * 4 + 0], reinterpret_cast<float*>(s_misc)[i * 4 + 1]);
     pref = mk(reinterpret_cast<float*>(s_misc)[i * 4 + 2], reinterpret_cast<float*>(s_misc)[i * 4 + 3]);
+    {   // how far does any agent of the arena move in this step?
+        const unsigned sp = wave_max_u32(active ? __float_as_uint(absSq(vel)) : 0u);
+        if ((tid & 63) == 63) atomicMax(&s_vmax2, sp);
+    }
     __syncthreads();  // every lane is done with the pre-step arena image
     CA_PSTAMP(9);
     if (h == 0) { s_px[i] = pos.x; s_py[i] = pos.y; }
@@ -520,7 +526,8 @@ __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
     if (p.flags & 2u) {  // CA_F_STATS: see ca_step.h for why K distances replace the scan of the arena
         int pairs = 0;
         const float crSq = sqr(R + R);
-        const float m2 = 2.02f * p.max_speed * p.time_step;
+        // (2 m of ca_step.h's argument, m = the arena's largest speed of this step x dt, measured: a bound from max_speed is not safe)
+        const float m2 = 2.0002f * __builtin_sqrtf(__uint_as_float(s_vmax2)) * p.time_step;
         bool scan_all = active && !(p.neighbor_dist >= R + R + m2);
         if (active && !scan_all) {
             float far2 = 0.0f;

@@ -83,6 +83,8 @@ __device__ __noinline__ void solve_many_obstacles(float4* tbl, int MLX, const Ob
 template <int KMAX, int BS, int ST, bool FUSE, int HELP = 1, int SMX = (ST > 0 ? ST : SMAX), bool ALAN = false>
 __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1) void step_kernel(const StepArgs p) {
     extern __shared__ float4 smem4[];
+    __shared__ unsigned s_vmax2;   // (BS > 64) the largest squared speed of the arena in this step, as float bits: see the pair count
+    if constexpr (BS > 64) { if (threadIdx.x == 0) s_vmax2 = 0u; }   // (barriers follow before its first use)
     CA_PRIO_START();
     // FUSE: the neighbour search runs at the head of this kernel instead of in a launch of its own (one
     // drain/fill less per step, and its dispatch skew overlaps useful work).  A lane later reads back only the
@@ -461,6 +463,10 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
         }
     }
 
+    if constexpr (BS > 64) {   // how far does any agent of the arena move in this step?  (one arena per workgroup at these sizes)
+        const unsigned sp = wave_max_u32(active ? __float_as_uint(absSq(vel)) : 0u);
+        if ((tid & 63) == 63) atomicMax(&s_vmax2, sp);
+    }
     __syncthreads();  // every lane is done with the pre-step arena image
     s_px[tid] = pos.x; s_py[tid] = pos.y;
     s_misc[tid * 4 + 0] = 0; s_misc[tid * 4 + 1] = 0; s_misc[tid * 4 + 2] = 0; s_misc[tid * 4 + 3] = 0;
@@ -468,7 +474,10 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
     int* red = s_misc + la * 4;  // per-arena: [0] not-done agents, [1] pairs, [2] wall hits, [3] goals
 
     if (p.flags & 2u) {  // CA_F_STATS
-        // Overlapping pairs (i < j, distance < 2R after the step).  Nobody moves farther than m = 1.01 max_speed dt,
+        // Overlapping pairs (i < j, distance < 2R after the step).  Nobody moves farther than m = the arena's largest speed of
+        // this step x dt (measured, not assumed: two agents that a reset drops onto the same spot can leave the linear programs
+        // at hundreds of times max_speed -- the oracle does the same -- and a bound of 1.01 max_speed dt then misses a pair: one
+        // in 2.8e7 agent-steps of the soak with auto-reset, profiles/r04_soak_parity.txt),
         // so an agent that overlaps this one now was within 2R + 2m of it when the neighbour list was built: if the
         // list is not full it holds every agent within neighbor_dist (>= 2R + 2m required), and if it is full and
         // its farthest member is still beyond 2R + 4m now, its K-th distance then was beyond 2R + 2m -- either way
@@ -477,7 +486,8 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
         // arena for those lanes.
         int pairs = 0;
         const float crSq = sqr(R + R);
-        const float m2 = 2.02f * p.max_speed * p.time_step;
+        float m2 = 0.0f;   // 2 m, a hair wide for the rounding of the update (NaN / infinite speeds fail every test below: full scan)
+        if constexpr (BS > 64) m2 = 2.0002f * __builtin_sqrtf(__uint_as_float(s_vmax2)) * p.time_step;
         bool scan_all = active && !(BS > 64 && p.neighbor_dist >= R + R + m2);  // arenas within one wave: the scan is cheaper
         if constexpr (BS > 64) if (active && !scan_all) {
             float far2 = 0.0f;

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from collision_avoidance_amd import _lib
+from collision_avoidance_amd import _lib, scenarios
 from oracle import oracle as o
 from tests import helpers as H
 
@@ -111,4 +111,38 @@ def test_scan_bound_does_not_trust_lists_written_by_the_caller():
         g.orca_step(stats=True); e.orca_step(flags=o.F_STATS)
     H.assert_state_equal(g, e, "after a reset")
     H.assert_stats_equal(g, e, "junk lists")
+    g.close()
+
+
+@pytest.mark.parametrize("pair", [True, False], ids=["two-lanes", "one-lane"])
+def test_pair_count_when_an_agent_is_thrown_across_the_arena(pair):
+    """The collision statistic of large arenas counts overlapping pairs through the neighbour lists, which is exact as long as
+    nobody moves farther in the step than the bound the argument uses.  A reset can drop two agents onto (nearly) the same spot;
+    the linear programs then leave one of them at hundreds of times max_speed -- in the oracle as here, bit for bit -- and it
+    lands next to agents that were never in its list.  The bound therefore is the arena's LARGEST SPEED OF THIS STEP, measured in
+    the kernel; with max_speed in its place this arena (arena 109 of the soak with seeds + 2000) counted 66 pairs instead of 67."""
+    import os
+    N, seed, arena = 180, 2021, 109
+    p = scenarios.bench_params(N, 5.0, 10)
+    old = os.environ.get("CA_PAIR")
+    if not pair:
+        os.environ["CA_PAIR"] = "0"
+    try:
+        g = H.make_gpu(1, N, "crowd", p, seed=seed, arena_offset=arena)
+    finally:
+        if not pair:
+            if old is None:
+                del os.environ["CA_PAIR"]
+            else:
+                os.environ["CA_PAIR"] = old
+    e = H.make_oracle(1, N, "crowd", p, seed=seed, arena_offset=arena)
+    assert g.launch_info()["lanes_per_agent"] == (2 if pair else 1)
+    g.reset(); e.reset()
+    act = np.random.RandomState(seed).uniform(-0.6, 0.6, (256, N)).astype(np.float32)[arena:arena + 1]
+    g.step(act, stats=True, autoreset=True)
+    e.step(act, flags=o.F_OBS | o.F_STATS | o.F_AUTORESET)
+    assert np.hypot(e.get(o.FLD_VEL_X), e.get(o.FLD_VEL_Y)).max() > 100.0       # the degenerate pair is there
+    H.assert_state_equal(g, e, "thrown agent", obs=True, reward=True)
+    H.assert_stats_equal(g, e, "thrown agent")
+    assert e.stats()["collisions"] == 67
     g.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: long GPU-vs-oracle parity soak (bit-exact state, lists, observation, reward, counters) on larger
-batches than the unit tests use.  Usage (GPU box): python tools/soak_parity.py [arenas] [steps] [seed offset]"""
+batches than the unit tests use.  Usage (GPU box): python tools/soak_parity.py [arenas] [steps] [seed offset] [case numbers]"""
 import os
 import sys
 import time
@@ -16,6 +16,7 @@ from tests import helpers as H
 A = int(sys.argv[1]) if len(sys.argv) > 1 else 192
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 seed_offset = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # other scenario draws and actions: an independent run
+only = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else None   # case numbers (0-based): a subset
 threads = max(1, min(32, len(os.sched_getaffinity(0))))
 cases = [("crowd", 64, scenarios.bench_params(64, 5.0, 10), 11), ("crowd", 64, scenarios.bench_params(64, 5.0, 10), 12),
          ("circle", 64, H.scenario_params("circle", 64), 3), ("doorway", 10, H.scenario_params("doorway", 10), 5),
@@ -31,7 +32,9 @@ cases = [("crowd", 64, scenarios.bench_params(64, 5.0, 10), 11), ("crowd", 64, s
          # their many-obstacle agents solved apart eight at a time (from 1281 workgroups: the tube at 50 agents per arena, blocks at
          # three 20-agent arenas per wave -- twice the arenas for that one)
          ("deadlock", 50, H.scenario_params("deadlock", 50), 27), ("blocks", 20, H.scenario_params("blocks", 20), 29, 2)]
-for scen, N, p, seed, *mult in cases:
+for ci, (scen, N, p, seed, *mult) in enumerate(cases):
+    if only is not None and ci not in only:
+        continue
     seed += seed_offset
     t0 = time.time()
     A_case = (A if N <= 64 else max(8, A // 16 if N <= 256 else A // 64)) * (mult[0] if mult else 1)
