@@ -2,7 +2,7 @@
 """Diagnostic: long GPU-vs-oracle parity soak of the ALAN online step (ALAN_true.py:569-628) on batches large enough for every form
 it takes -- inside the four-lanes kernel (one launch per 256 steps of a rollout), inside the one-lane kernels (obstacle lists of 4 and
 16, many-obstacle agents solved apart), per-arena freezing at the episode's end (run_sim, ALAN:106-123) -- state, lists, fp64 weights
-and times, actions, arrival steps and counters, bit for bit.  Usage (GPU box): python tools/soak_alan.py [steps]"""
+and times, actions, arrival steps and counters, bit for bit.  Usage (GPU box): python tools/soak_alan.py [steps] [seed offset]"""
 import os
 import sys
 import time
@@ -16,6 +16,7 @@ from oracle import oracle as o
 from tests import helpers as H
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+seed_offset = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # other scenario draws (and, through them, other bandit draws)
 ACTS9 = [(1, 0), (0.70711, 0.70711), (0, 1), (-0.70711, 0.70711), (-1, 0), (-0.70711, -0.70711), (0, -1), (0.70711, -0.70711), (0.5, 0.1)]
 cases = [("crowd", 16, 512, alan.DEFAULT_ACTIONS, 1),      # four lanes per agent: the bandit inside a one-launch rollout
          ("crowd", 64, 2048, alan.DEFAULT_ACTIONS, 3),     # one lane per agent, one wave per arena
@@ -26,6 +27,7 @@ cases = [("crowd", 16, 512, alan.DEFAULT_ACTIONS, 1),      # four lanes per agen
          ("deadlock", 50, 1100, ACTS9, 13)]                # the LDS line table (a batch the chip holds at once)
 total = 0
 for scen, N, A, acts, seed in cases:
+    seed += seed_offset
     t0 = time.time()
     p = H.scenario_params(scen, N, max_step=steps - 40)    # the cap ends the episodes of the slow arenas inside the run
     g = H.make_gpu(A, N, scen, p, seed=seed)
