@@ -202,7 +202,11 @@ def obs_array(env, d):
     return np.array([d['agent_%d' % i] for i in range(env.numAgents)], np.float64)
 
 
-def gen_env_fixture(name, n_agents, seed, n_steps, reset_at, obs_every, spawn_squeeze=None):
+def gen_env_fixture(name, n_agents, seed, n_steps, reset_at, obs_every, spawn_squeeze=None, act_scale=None,
+                    orca_every=17, reset_on_done=False, after_reset_steps=0):
+    """act_scale: actions ~ U(-act_scale, act_scale) (agents pass the door); reset_on_done: the caller's protocol
+    (run_rllib.py's workers): the step after '__all__' comes back True is preceded by env.reset(), and the run ends
+    after_reset_steps steps later -- the END of an episode: env.py:352-365, 404-414, 461-488."""
     import warnings
     warnings.simplefilter("ignore")
     import collision_avoidance.envs.collision_avoidence_env as refenv
@@ -227,14 +231,19 @@ def gen_env_fixture(name, n_agents, seed, n_steps, reset_at, obs_every, spawn_sq
                obs=[], obs_steps=[], reset_steps=[], reset_pos=[], reset_obs=[], kind=[])
     p, v, pf, t = sim_state(env)
     init = dict(pos0=p, vel0=v, pref0=pf, tgt0=t, obs0=obs_array(env, env.gym_obs))
+    pending_reset, last = False, n_steps
+    rec["step_count"] = []
     for s in range(n_steps):
-        if s in reset_at:
+        if s >= last:
+            break
+        if s in reset_at or pending_reset:
+            pending_reset = False
             with contextlib.redirect_stdout(io.StringIO()):
                 o = env.reset()
             p, v, pf, t = sim_state(env)
             rec["reset_steps"].append(s); rec["reset_pos"].append(p); rec["reset_obs"].append(obs_array(env, o))
         kind = 0
-        if s % 17 == 16:
+        if orca_every and s % orca_every == orca_every - 1:
             kind = 1  # an orca_step (env.py:447-458) in between
             with contextlib.redirect_stdout(io.StringIO()):
                 env.orca_step((0, 0))
@@ -243,25 +252,34 @@ def gen_env_fixture(name, n_agents, seed, n_steps, reset_at, obs_every, spawn_sq
             done_all = False
             o = env.gym_obs
         else:
-            act = rng.uniform(-np.pi, np.pi, n_agents).astype(np.float32) * (0.35 if s % 3 else 1.0)
+            if act_scale is None:
+                act = rng.uniform(-np.pi, np.pi, n_agents).astype(np.float32) * (0.35 if s % 3 else 1.0)
+            else:
+                act = rng.uniform(-act_scale, act_scale, n_agents).astype(np.float32)
             with contextlib.redirect_stdout(io.StringIO()):
                 o, r, d, _ = env.step({'agent_%d' % i: act[i:i + 1] for i in range(n_agents)})
             rew = np.array([float(r['agent_%d' % i]) for i in range(n_agents)], np.float64)
             done_all = bool(d['__all__'])
+            if done_all and reset_on_done and last == n_steps:
+                pending_reset, last = True, s + 1 + after_reset_steps
+        rec["step_count"].append(env.step_count)
         p, v, pf, t = sim_state(env)
         rec["kind"].append(kind); rec["actions"].append(act); rec["pos"].append(p); rec["vel"].append(v)
         rec["pref"].append(pf); rec["tgt"].append(t); rec["reward"].append(rew)
         rec["done_all"].append(done_all); rec["agents_done"].append(np.array(env.agents_done, np.int32))
         if s % obs_every == 0 or s < 24 or kind == 1:
             rec["obs"].append(obs_array(env, o)); rec["obs_steps"].append(s)
+    if not reset_on_done:
+        del rec["step_count"]         # the fixtures of rounds 1-4 regenerate byte for byte
     out = {k: np.array(v) for k, v in rec.items()}
     out.update(init)
     out["n_agents"] = np.int32(n_agents)
     out["step_count_final"] = np.int32(env.step_count)
     np.savez_compressed(os.path.join(HERE, name), **out)
     nz = int((np.abs(out["obs"]) > 0).sum())
-    print("%s: %d steps, %d obs snapshots (%d non-zero obs entries), done_all any=%s"
-          % (name, n_steps, len(rec["obs_steps"]), nz, bool(np.any(out["done_all"]))))
+    print("%s: %d steps, %d obs snapshots (%d non-zero obs entries), done_all any=%s, agents done %d, resets at %s"
+          % (name, len(rec["kind"]), len(rec["obs_steps"]), nz, bool(np.any(out["done_all"])),
+             int(out["agents_done"].max(axis=0).sum()), rec["reset_steps"]))
 
 
 def gen_alan_scenarios():
@@ -456,6 +474,91 @@ def gen_alan_blocks():
         [int(out["w%d_steps" % i]) for i in range(3)], [int(out["w%d_success" % i]) for i in range(3)],
         [out["w%d_obst" % i][1][0].tolist() for i in range(3)]))
 
+def gen_alan_finished():
+    """Episodes that END, through the reference's OWN loop: run_sim(mode) (ALAN_true.py:106-131) is called as it is --
+    the recorder sits in done_test, which the loop calls once per step after its counter -- for runs where every agent
+    arrives (success -> break, :121-123; total_time, TTime over a finished run, :125-131) and one that runs into
+    max_step with an agent still on its way.  mode 1 = online_step with numpy's choice replaced as in gen_alan_online."""
+    import warnings
+    warnings.simplefilter("ignore")
+    import collision_avoidance.ALAN.ALAN_true as alan
+    real_choice = np.random.choice
+    out = {}
+    acts3 = [(1, 0), (0.7071067811865476, 0.7071067811865476), (0.7071067811865476, -0.7071067811865476)]
+    cases = (("circle", 8, 0, None), ("crowd", 10, 0, None), ("incoming", 5, 0, None), ("congested", 6, 0, None),
+             ("crowd", 6, 0, None), ("circle", 8, 1, acts3), ("crowd", 10, 1, None))
+    seeds = (811, 814, 812, 813, 810, 821, 824)
+    for ci, ((scen, n, mode, actions), seed) in enumerate(zip(cases, seeds)):
+        alan.uniform = _Stream(seed)
+        urng = np.random.RandomState(seed + 100)
+        drawn = []
+
+        def choice(a, size=None, p=None):
+            cdf = np.asarray(p, np.float64).cumsum()
+            cdf /= cdf[-1]
+            u = urng.random_sample()
+            drawn.append(u)
+            return np.array([cdf.searchsorted(u, side='right')])
+        np.random.choice = choice
+        try:
+            sim = alan.Collision_Avoidance_Sim(numAgents=n, scenario=scen, online_actions=actions, visualize=False)
+            sim.reset(actions)
+            key = "c%d_" % ci
+            out[key + "scenario"] = np.array(scen)
+            out[key + "mode"] = np.int32(mode)
+            out[key + "actions"] = np.array(sim.online_actions, np.float64)
+            out[key + "pos0"] = np.array([sim.sim.getAgentPosition(i) for i in range(n)], np.float32)
+            out[key + "vel0"] = np.array([sim.sim.getAgentVelocity(i) for i in range(n)], np.float32)
+            out[key + "pref0"] = np.array([sim.sim.getAgentPrefVelocity(i) for i in range(n)], np.float32)
+            out[key + "goal0"] = np.array([sim.world["targets_pos"][i][0] for i in range(n)], np.float64)
+            out[key + "goal20"] = np.array([sim.world["targets_pos"][i][1] for i in range(n)], np.float64)
+            rec = dict(u=[], pos=[], vel=[], done=[])
+            inner = sim.done_test
+
+            def recording_done_test():
+                r = inner()
+                rec["u"].append(list(drawn)); del drawn[:]
+                rec["pos"].append([sim.sim.getAgentPosition(i) for i in range(n)])
+                rec["vel"].append([sim.sim.getAgentVelocity(i) for i in range(n)])
+                rec["done"].append(list(sim.agents_done))
+                return r
+            sim.done_test = recording_done_test
+            success, total_time, ttime, min_ttime = sim.run_sim(mode)      # the reference's loop itself
+            every = 5
+            out[key + "u"] = np.array(rec["u"], np.float64)                  # [steps, n] (mode 1) or [steps, 0]
+            out[key + "pos"] = np.array(rec["pos"], np.float32)[::every]
+            out[key + "vel"] = np.array(rec["vel"], np.float32)[::every]
+            out[key + "done"] = np.array(rec["done"], np.int32)
+            out[key + "pos_last"] = np.array(rec["pos"][-1], np.float32)
+            out[key + "vel_last"] = np.array(rec["vel"][-1], np.float32)
+            out[key + "steps"] = np.int32(sim.step_count)
+            out[key + "success"] = np.int32(bool(success))
+            out[key + "total_time"] = np.float64(total_time)
+            out[key + "TTime"] = np.float64(ttime)
+            out[key + "min_TTime"] = np.float64(min_ttime)
+            out[key + "agents_time"] = np.array(sim.agents_time, np.float64)
+            out[key + "goal_last"] = np.array([sim.world["targets_pos"][i][0] for i in range(n)], np.float64)
+            out[key + "max_step"] = np.int32(sim.max_step)
+            if mode == 1:
+                out[key + "w_last"] = np.array(sim.world["action_weights"], np.float64)
+                out[key + "t_last"] = np.array(sim.world["action_times"], np.float64)
+        finally:
+            np.random.choice = real_choice
+    out["n_cases"] = np.int32(len(cases))
+    np.savez_compressed(os.path.join(HERE, "alan_finished.npz"), **out)
+    print("alan_finished.npz: %d cases, steps %s, success %s" % (
+        len(cases), [int(out["c%d_steps" % i]) for i in range(len(cases))], [int(out["c%d_success" % i]) for i in range(len(cases))]))
+
+
+def gen_round5():
+    """The END of an episode (round 5): agents_done / the (-10, 5) retarget / '__all__' by the step cap and by the
+    last arrival / reset() after an episode keeping the swapped targets; run_sim episodes that finish."""
+    gen_env_fixture("env_doorway_n6_episode.npz", 6, seed=21, n_steps=1200, reset_at=(), obs_every=10, act_scale=0.15,
+                    orca_every=None, reset_on_done=True, after_reset_steps=100)
+    gen_env_fixture("env_doorway_n4_all_done.npz", 4, seed=24, n_steps=1200, reset_at=(), obs_every=10, act_scale=0.05,
+                    orca_every=None, reset_on_done=True, after_reset_steps=100)
+    gen_alan_finished()
+
 
 if __name__ == "__main__":
     if not os.path.isdir(REF):
@@ -464,6 +567,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "blocks":   # only the file added in round 2
         install_stubs()
         gen_alan_blocks()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "round5":   # only the files added in round 5
+        install_stubs()
+        gen_round5()
         sys.exit(0)
     gen_utils_vectors()
     install_stubs()
@@ -474,3 +581,4 @@ if __name__ == "__main__":
     gen_alan_online()
     gen_alan_orca()
     gen_alan_blocks()
+    gen_round5()

@@ -9,7 +9,7 @@ from tools import alan_actions
 from collision_avoidance_amd import _lib, alan, scenarios
 from oracle import oracle as o
 from tests import helpers as H
-from tests.test_oracle_alan import load_case, setup_env
+from tests.test_oracle_alan import assert_vel_close, load_case, setup_env
 
 pytestmark = pytest.mark.gpu
 
@@ -132,6 +132,7 @@ def test_gpu_replays_reference_alan_online_runs(golden_dir, ci):
             np.testing.assert_array_equal(env.get(_lib.FLD_POS_X)[0], c["pos"][s][:, 0], err_msg="step %d" % s)
             np.testing.assert_array_equal(env.get(_lib.FLD_POS_Y)[0], c["pos"][s][:, 1])
             np.testing.assert_array_equal(env.get(_lib.FLD_VEL_X)[0], c["vel"][s][:, 0])
+            assert_vel_close(env.get(_lib.FLD_VEL_Y)[0], c["vel"][s][:, 1], "step %d" % s)
             np.testing.assert_array_equal(env.get(_lib.FLD_AGENT_DONE)[0], c["done"][s])
         if s % 10 == 0:
             np.testing.assert_allclose(env.get(_lib.FLD_ALAN_WEIGHTS)[0], c["w"][s // 10], rtol=0, atol=1e-13)
@@ -221,6 +222,28 @@ def test_gpu_replays_reference_orca_episode_loop(golden_dir, ci):
     env, n, p = setup_env(make, c, lambda e, f, v: e.set(f, v), _lib)
     env.set(_lib.FLD_PREF_X, c["pref0"][:, 0]); env.set(_lib.FLD_PREF_Y, c["pref0"][:, 1])
     replay_orca_episode(env, c, _lib, lambda e: e.orca_step(), lambda e, f: e.get(f))
+    env.close()
+
+
+@pytest.mark.parametrize("ci", range(7))
+def test_gpu_replays_reference_episodes_that_finish(golden_dir, ci):
+    """run_sim(0) and run_sim(1) of the reference recorded to their END (tests/golden/alan_finished.npz: every agent
+    arrives and the loop breaks, or the run hits max_step) through ca_orca_step / ca_alan_step: the arena's done flag at
+    exactly the reference's last step, total_time, arrival times, TTime, min_TTime, the swapped targets."""
+    from tests.test_oracle_alan import load_finished_case, replay_finished_episode
+    c = load_finished_case(golden_dir, ci)
+
+    def make(n, scen, p):
+        return H.make_gpu(1, n, scen, p, max_obst_neighbors=8)
+    env, n, p = setup_env(make, c, lambda e, f, v: e.set(f, v), _lib)
+    env.set(_lib.FLD_PREF_X, c["pref0"][:, 0]); env.set(_lib.FLD_PREF_Y, c["pref0"][:, 1])
+    if int(c["mode"]) == 1:
+        env.alan_configure(c["actions"])
+        replay_finished_episode(env, c, _lib, lambda e, s: e.alan_step(c["u"][s]), lambda e, f: e.get(f), p)
+        np.testing.assert_allclose(env.get(_lib.FLD_ALAN_WEIGHTS)[0], c["w_last"], rtol=0, atol=1e-13)
+        np.testing.assert_array_equal(env.get(_lib.FLD_ALAN_TIMES)[0], c["t_last"])
+    else:
+        replay_finished_episode(env, c, _lib, lambda e, s: e.orca_step(), lambda e, f: e.get(f), p)
     env.close()
 
 

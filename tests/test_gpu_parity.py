@@ -321,7 +321,8 @@ def _golden_replay_gpu(golden_dir, name):
     g = np.load(os.path.join(golden_dir, name))
     n = int(g["n_agents"])
     env = H.make_gpu(1, n, "doorway", scenarios.env_params(), max_obst_neighbors=8)
-    env.set(_lib.FLD_POS_X, g["pos0"][:, 0]); env.set(_lib.FLD_POS_Y, g["pos0"][:, 1])
+    assert (env.get(_lib.FLD_GOAL2_X) == -10.0).all() and (env.get(_lib.FLD_GOAL2_Y) == 5.0).all()   # env.py:361: the doorway
+    env.set(_lib.FLD_POS_X, g["pos0"][:, 0]); env.set(_lib.FLD_POS_Y, g["pos0"][:, 1])               # world's own retarget
     env.set(_lib.FLD_VEL_X, g["vel0"][:, 0]); env.set(_lib.FLD_VEL_Y, g["vel0"][:, 1])
     env.set(_lib.FLD_PREF_X, g["pref0"][:, 0]); env.set(_lib.FLD_PREF_Y, g["pref0"][:, 1])
     env.set(_lib.FLD_GOAL_X, g["tgt0"][:, 0]); env.set(_lib.FLD_GOAL_Y, g["tgt0"][:, 1])
@@ -346,8 +347,14 @@ def _golden_replay_gpu(golden_dir, name):
         np.testing.assert_array_equal(st["pos_x"][0], g["pos"][s][:, 0], err_msg="step %d" % s)
         np.testing.assert_array_equal(st["pos_y"][0], g["pos"][s][:, 1])
         np.testing.assert_array_equal(st["vel_x"][0], g["vel"][s][:, 0])
+        np.testing.assert_array_equal(st["vel_y"][0], g["vel"][s][:, 1])
         np.testing.assert_array_equal(st["pref_x"][0], g["pref"][s][:, 0])
+        np.testing.assert_array_equal(st["pref_y"][0], g["pref"][s][:, 1])
         np.testing.assert_array_equal(st["agent_done"][0], g["agents_done"][s])
+        np.testing.assert_array_equal(st["goal_x"][0], g["tgt"][s][:, 0])       # the (-10, 5) retarget, kept by reset()
+        np.testing.assert_array_equal(st["goal_y"][0], g["tgt"][s][:, 1])
+        if "step_count" in g.files:                                              # the counter, its cap, its reset
+            assert int(st["step_count"][0]) == int(g["step_count"][s]), s
         if s in obs_at:
             err = np.abs(ob[0].astype(np.float64) - g["obs"][obs_at[s]])
             bad += count_bad(err, ("step", s)); tot += n * 16
@@ -355,13 +362,54 @@ def _golden_replay_gpu(golden_dir, name):
     return bad, tot
 
 
-@pytest.mark.parametrize("name", ["env_doorway_n10.npz", "env_doorway_n6_dense.npz"])
+@pytest.mark.parametrize("name", ["env_doorway_n10.npz", "env_doorway_n6_dense.npz", "env_doorway_n6_episode.npz",
+                                  "env_doorway_n4_all_done.npz"])
 def test_gpu_replays_reference_env_loop_golden(golden_dir, name):
     """Golden runs of the reference's own env loop (reset / step / orca_step / _get_obs / done_test around doStep) --
     recorded with the oracle's ORCA standing in for the absent rvo2 module (tests/golden/make_golden.py), so this pins the
     Python loops and the laser observation, not the ORCA solver itself."""
     bad, tot = _golden_replay_gpu(golden_dir, name)
     assert bad <= max(2, tot // 500), (bad, tot)
+
+
+@pytest.mark.parametrize("name", ["env_doorway_n6_episode.npz", "env_doorway_n4_all_done.npz"])
+def test_gpu_autoreset_at_the_recorded_end_of_an_episode(golden_dir, name):
+    """The recorded episode again, but with the reset taken INSIDE the step that ends it (CA_F_AUTORESET) instead of by
+    the caller: up to that step the run is the reference's; the step itself reports '__all__' and leaves what the
+    reference's reset() leaves (env.py:461-488) -- counter and done flags zeroed, the swapped (-10, 5) targets KEPT, new
+    positions inside the spawn box (drawn by the handle's own stream: not the fixture's) -- and equals the oracle
+    doing the same."""
+    from collision_avoidance_amd import _lib
+    g = np.load(os.path.join(golden_dir, name))
+    n = int(g["n_agents"])
+    r = int(g["reset_steps"][0])
+    env = H.make_gpu(1, n, "doorway", scenarios.env_params(), max_obst_neighbors=8, seed=3)
+    orc = H.make_oracle(1, n, "doorway", scenarios.env_params(), max_obst_neighbors=8, seed=3)
+    for e, F in ((env, _lib), (orc, o)):
+        for f, v in (("POS_X", g["pos0"][:, 0]), ("POS_Y", g["pos0"][:, 1]), ("VEL_X", g["vel0"][:, 0]), ("VEL_Y", g["vel0"][:, 1]),
+                     ("PREF_X", g["pref0"][:, 0]), ("PREF_Y", g["pref0"][:, 1]), ("GOAL_X", g["tgt0"][:, 0]), ("GOAL_Y", g["tgt0"][:, 1])):
+            e.set(getattr(F, "FLD_" + f), v)
+    for s in range(r):
+        _, _, done, _ = env.step(g["actions"][s], autoreset=True, stats=True)
+        orc.step(g["actions"][s], flags=o.F_OBS | o.F_STATS | o.F_AUTORESET)
+        assert bool(done[0]) == bool(g["done_all"][s]), s
+        if s < r - 1:
+            st = env.state()
+            np.testing.assert_array_equal(st["pos_x"][0], g["pos"][s][:, 0], err_msg="step %d" % s)
+            np.testing.assert_array_equal(st["agent_done"][0], g["agents_done"][s])
+    st = env.state()
+    arrived = g["agents_done"][r - 1] == 1
+    assert int(st["step_count"][0]) == 0 and st["agent_done"][0].max() == 0
+    assert (st["goal_x"][0][arrived] == -10.0).all() and (st["goal_y"][0] == 5.0).all() and (st["goal_x"][0][~arrived] == 1.0).all()
+    assert (st["pos_x"][0] >= 5.0).all() and (st["pos_x"][0] <= 10.0).all() and (st["pos_y"][0] >= 0).all() and (st["pos_y"][0] <= 10.0).all()
+    assert int(env.get(_lib.FLD_EPISODE)[0]) == 1 and env.stats()["episodes"] == 1
+    H.assert_state_equal(env, orc, name + " after the autoreset", obs=True, reward=True)
+    for s in range(r, r + 20):                         # and the next episode starts like any other
+        env.step(g["actions"][s], autoreset=True, stats=True)
+        orc.step(g["actions"][s], flags=o.F_OBS | o.F_STATS | o.F_AUTORESET)
+    H.assert_state_equal(env, orc, name + " 20 steps into the next episode", obs=True, reward=True)
+    H.assert_stats_equal(env, orc, name)
+    env.close()
 
 
 def test_dropin_env_api():

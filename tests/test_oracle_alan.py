@@ -9,6 +9,29 @@ from collision_avoidance_amd import scenarios
 from oracle import oracle as o
 
 
+# The reference forms an agent's preferred velocity as (cos(a), sin(a)), a = np.arctan2(dy, dx) in fp64 (ALAN_true.py:489-495,
+# env.py:156-162): `a` is quantised to 2^-51 near +-pi, so a component that should be 1.7e-8 comes out with an ABSOLUTE
+# error of up to ~4.4e-16 -- and WHICH error depends on the machine: numpy's arctan2 is SIMD-dispatched (AVX512 SVML in the
+# container that wrote the fixtures: it differs from libm's atan2 in the last bit in 7.7 % of 200 000 random directions).
+# The build takes the direction as the normalised vector (accurate to an fp64 ulp of the component itself).  The two
+# agree bit for bit after rounding to fp32 unless a component is tiny (|c| < ~1e-7: an agent heading exactly along an
+# axis: the "incoming" and "deadlock" worlds).  So: positions exact; velocity components exact, except that a component
+# below 1e-6 in magnitude may differ by the quantisation plus the one fp32 ulp it can push the rounding over.
+PREF_ANGLE_TOL = 4.5e-16
+TINY_COMPONENT = 1e-6
+
+
+def assert_vel_close(actual, golden, msg=""):
+    """Exact, or -- see PREF_ANGLE_TOL -- within the reference's own angle quantisation; returns 1 for a non-exact match."""
+    if np.array_equal(actual, golden):
+        return 0
+    a, g = actual.astype(np.float64), golden.astype(np.float64)
+    bad = a != g
+    assert (np.abs(g[bad]) < TINY_COMPONENT).all(), (msg, a[bad], g[bad])
+    assert (np.abs(a[bad] - g[bad]) <= PREF_ANGLE_TOL + 2.0 ** -23 * np.abs(g[bad])).all(), (msg, a[bad], g[bad])
+    return 1
+
+
 def load_case(golden_dir, ci):
     g = np.load(os.path.join(golden_dir, "alan_online.npz"))
     key = "c%d_" % ci
@@ -46,6 +69,7 @@ def test_online_step_matches_reference(golden_dir, ci):
         np.testing.assert_array_equal(env.get(o.FLD_POS_X)[0], c["pos"][s][:, 0], err_msg="step %d" % s)
         np.testing.assert_array_equal(env.get(o.FLD_POS_Y)[0], c["pos"][s][:, 1])
         np.testing.assert_array_equal(env.get(o.FLD_VEL_X)[0], c["vel"][s][:, 0])
+        assert_vel_close(env.get(o.FLD_VEL_Y)[0], c["vel"][s][:, 1], "step %d" % s)
         np.testing.assert_array_equal(env.get(o.FLD_AGENT_DONE)[0], c["done"][s])
         if s % 10 == 0:
             np.testing.assert_allclose(env.get(o.FLD_ALAN_WEIGHTS)[0], c["w"][s // 10], rtol=0, atol=1e-13)
@@ -125,6 +149,7 @@ def replay_orca_episode(env, c, F, step, get):
             np.testing.assert_array_equal(get(env, F.FLD_POS_X)[0], c["pos"][s // 5][:, 0], err_msg="step %d" % s)
             np.testing.assert_array_equal(get(env, F.FLD_POS_Y)[0], c["pos"][s // 5][:, 1])
             np.testing.assert_array_equal(get(env, F.FLD_VEL_X)[0], c["vel"][s // 5][:, 0])
+            assert_vel_close(get(env, F.FLD_VEL_Y)[0], c["vel"][s // 5][:, 1], "step %d" % s)
             np.testing.assert_array_equal(get(env, F.FLD_AGENT_DONE)[0], c["done"][s // 5])
     np.testing.assert_array_equal(get(env, F.FLD_POS_X)[0], c["pos_last"][:, 0])
     np.testing.assert_array_equal(get(env, F.FLD_AGENT_DONE)[0], c["done_last"])
@@ -146,3 +171,76 @@ def test_plain_orca_episode_matches_reference(golden_dir, ci):
     env, n, p = setup_env(make, c, lambda e, f, v: e.set(f, v), o)
     env.set(o.FLD_PREF_X, c["pref0"][:, 0]); env.set(o.FLD_PREF_Y, c["pref0"][:, 1])   # set by _init_world (update_pref_vel)
     replay_orca_episode(env, c, o, lambda e: e.orca_step(flags=0), lambda e, f: e.get(f))
+
+
+# ---- episodes that END (round 5): run_sim itself, recorded from inside its own loop -------------------------------
+N_FINISHED = 7
+
+
+def load_finished_case(golden_dir, ci):
+    g = np.load(os.path.join(golden_dir, "alan_finished.npz"))
+    key = "c%d_" % ci
+    return {k[len(key):]: g[k] for k in g.files if k.startswith(key)}
+
+
+def replay_finished_episode(env, c, F, step, get, p):
+    """The reference's run_sim(mode) (ALAN_true.py:106-131) replayed to its END: `step(env, s)` advances one step of
+    the loop (orca_step or online_step + counter + done_test); the arena's done flag must come true at exactly the
+    step where the reference's loop broke (success) or never (the run into max_step); then total_time, the arrival
+    times, TTime, min_TTime and the swapped targets of :547-566."""
+    from collision_avoidance_amd import alan
+    steps, success = int(c["steps"]), bool(c["success"])
+    inexact = 0
+    for s in range(steps):
+        assert not bool(get(env, F.FLD_ARENA_DONE)[0]), "arena done before step %d of %d" % (s, steps)
+        step(env, s)
+        np.testing.assert_array_equal(get(env, F.FLD_AGENT_DONE)[0], c["done"][s], err_msg="step %d" % s)
+        if s % 5 == 0:
+            np.testing.assert_array_equal(get(env, F.FLD_POS_X)[0], c["pos"][s // 5][:, 0], err_msg="step %d" % s)
+            np.testing.assert_array_equal(get(env, F.FLD_POS_Y)[0], c["pos"][s // 5][:, 1])
+            inexact += assert_vel_close(get(env, F.FLD_VEL_X)[0], c["vel"][s // 5][:, 0], "step %d" % s)
+            inexact += assert_vel_close(get(env, F.FLD_VEL_Y)[0], c["vel"][s // 5][:, 1], "step %d" % s)
+    assert inexact == 0 or str(c["scenario"]) in ("incoming", "deadlock"), inexact   # only axis-aligned worlds meet the quantisation
+    np.testing.assert_array_equal(get(env, F.FLD_POS_X)[0], c["pos_last"][:, 0])
+    np.testing.assert_array_equal(get(env, F.FLD_POS_Y)[0], c["pos_last"][:, 1])
+    assert_vel_close(get(env, F.FLD_VEL_X)[0], c["vel_last"][:, 0])
+    assert_vel_close(get(env, F.FLD_VEL_Y)[0], c["vel_last"][:, 1])
+    # success -> break (:121-123); otherwise the loop ran out at max_step (the build's arena_done then is the step cap)
+    assert int(get(env, F.FLD_STEP_COUNT)[0]) == steps
+    assert bool(get(env, F.FLD_AGENT_DONE)[0].all()) == success
+    assert bool(get(env, F.FLD_ARENA_DONE)[0]) and (success or steps == int(c["max_step"]))
+    assert steps * p["time_step"] == float(c["total_time"])                                   # :125
+    times = alan.agents_time(get(env, F.FLD_ARRIVE_STEP)[0], get(env, F.FLD_AGENT_DONE)[0], p["time_step"], int(c["max_step"]))
+    np.testing.assert_allclose(times, c["agents_time"], rtol=0, atol=1e-12)
+    assert abs(alan.ttime(times) - float(c["TTime"])) < 1e-9                                  # :126-130
+    assert abs(alan.min_ttime(c["pos0"], c["goal0"], p["max_speed"]) - float(c["min_TTime"])) < 1e-12
+    np.testing.assert_array_equal(get(env, F.FLD_GOAL_X)[0], c["goal_last"][:, 0])            # :563-564
+    np.testing.assert_array_equal(get(env, F.FLD_GOAL_Y)[0], c["goal_last"][:, 1])
+
+
+def test_finished_fixture_reaches_the_end_of_run_sim(golden_dir):
+    succ = [int(load_finished_case(golden_dir, ci)["success"]) for ci in range(N_FINISHED)]
+    modes = [int(load_finished_case(golden_dir, ci)["mode"]) for ci in range(N_FINISHED)]
+    assert succ == [1, 1, 1, 1, 0, 1, 1] and modes == [0, 0, 0, 0, 0, 1, 1]
+    c = load_finished_case(golden_dir, 4)
+    assert int(c["steps"]) == int(c["max_step"]) and c["done"][-1].min() == 0     # ran into the cap, one agent on its way
+
+
+@pytest.mark.parametrize("ci", range(N_FINISHED))
+def test_finished_episode_matches_reference(golden_dir, ci):
+    c = load_finished_case(golden_dir, ci)
+
+    def make(n, scen, p):
+        e = o.OracleEnv(o.make_config(n_arenas=1, n_agents=n, max_obst_neighbors=16, **p))
+        e.set_obstacles(scenarios.obstacles(scen, n))
+        e.init_scenario(scenarios.SCENARIO_IDS[scen])
+        return e
+    env, n, p = setup_env(make, c, lambda e, f, v: e.set(f, v), o)
+    env.set(o.FLD_PREF_X, c["pref0"][:, 0]); env.set(o.FLD_PREF_Y, c["pref0"][:, 1])
+    if int(c["mode"]) == 1:
+        env.alan_configure(c["actions"])
+        replay_finished_episode(env, c, o, lambda e, s: e.alan_step(c["u"][s], prec=o.PREC_F64), lambda e, f: e.get(f), p)
+        np.testing.assert_allclose(env.get(o.FLD_ALAN_WEIGHTS)[0], c["w_last"], rtol=0, atol=1e-13)
+        np.testing.assert_array_equal(env.get(o.FLD_ALAN_TIMES)[0], c["t_last"])
+    else:
+        replay_finished_episode(env, c, o, lambda e, s: e.orca_step(flags=0), lambda e, f: e.get(f), p)

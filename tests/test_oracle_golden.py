@@ -109,6 +109,9 @@ def _replay(golden_dir, name, prec, margins=None):
         np.testing.assert_array_equal(st["pref_y"][0], g["pref"][s][:, 1])
         np.testing.assert_array_equal(st["agent_done"][0], g["agents_done"][s])
         np.testing.assert_array_equal(st["goal_x"][0], g["tgt"][s][:, 0])
+        np.testing.assert_array_equal(st["goal_y"][0], g["tgt"][s][:, 1])
+        if "step_count" in g.files:          # the episode fixtures of round 5: the counter and its cap, step by step
+            assert int(env.get(o.FLD_STEP_COUNT)[0]) == int(g["step_count"][s]), s
         if s in obs_at:
             err = np.abs(env.get(obs_fld)[0].astype(np.float64) - g["obs"][obs_at[s]])
             obs_bad += count_bad(err, tol, margins, ("step", s), env, prec, n); obs_tot += n * 16
@@ -116,7 +119,29 @@ def _replay(golden_dir, name, prec, margins=None):
     return obs_bad, obs_tot
 
 
-@pytest.mark.parametrize("name", ["env_doorway_n10.npz", "env_doorway_n6_dense.npz"])
+ENV_FIXTURES = ["env_doorway_n10.npz", "env_doorway_n6_dense.npz", "env_doorway_n6_episode.npz", "env_doorway_n4_all_done.npz"]
+
+
+def test_episode_fixtures_reach_the_end_of_an_episode(golden_dir):
+    """What the round-5 fixtures are FOR (env.py:352-365, 404-414, 461-488): an agent arrives and is retargeted to
+    (-10, 5); '__all__' comes true by the step cap with agents still on their way, and by the last arrival before
+    the cap; reset() zeroes the counter and the flags and keeps the swapped targets."""
+    g = np.load(os.path.join(golden_dir, "env_doorway_n6_episode.npz"))
+    r = int(g["reset_steps"][0])
+    assert g["agents_done"][:r].max() == 1 and g["agents_done"][r - 1].min() == 0          # some arrived, not all
+    assert bool(g["done_all"][r - 1]) and not g["done_all"][:r - 1].any() and int(g["step_count"][r - 1]) == 1000   # the cap
+    arrived = g["agents_done"][r - 1] == 1
+    assert (g["tgt"][r - 1][arrived] == (-10.0, 5.0)).all() and (g["tgt"][r - 1][~arrived] == (1.0, 5.0)).all()
+    assert int(g["step_count"][r]) == 1 and (g["tgt"][r][arrived] == (-10.0, 5.0)).all()    # reset keeps the swapped targets
+    assert len(g["kind"]) == r + 100 and not g["done_all"][r:].any()
+    g = np.load(os.path.join(golden_dir, "env_doorway_n4_all_done.npz"))
+    r = int(g["reset_steps"][0])
+    assert g["agents_done"][r - 1].min() == 1 and bool(g["done_all"][r - 1]) and int(g["step_count"][r - 1]) < 1000
+    assert (g["tgt"][r - 1] == (-10.0, 5.0)).all() and (g["tgt"][-1] == (-10.0, 5.0)).all()
+    assert g["agents_done"][r].max() == 0                                                   # ... and clears the flags
+
+
+@pytest.mark.parametrize("name", ENV_FIXTURES)
 def test_env_loop_f64_matches_reference(golden_dir, name):
     bad, tot = _replay(golden_dir, name, o.PREC_F64)
     assert tot > 1000 and bad == 0, (bad, tot)
@@ -130,7 +155,7 @@ def flip_margins(golden_dir, name):
     return margins
 
 
-@pytest.mark.parametrize("name", ["env_doorway_n10.npz", "env_doorway_n6_dense.npz"])
+@pytest.mark.parametrize("name", ENV_FIXTURES)
 def test_env_loop_f32_close_to_reference(golden_dir, name):
     """fp32 observation arithmetic against the reference's fp64: within 3e-5 except rays that graze a segment end
     (counted, bounded, and each one checked to BE such a ray)."""
