@@ -62,6 +62,9 @@ def parse():
                     help="--mode orca: steps per ca_rollout call (the ORCA-only policy rollout of env.py:570-573 / ALAN:106-123); "
                          "1 = one ca_orca_step call per step")
     ap.add_argument("--arenas", type=int, default=None, help="diagnostic: override the workload's arena count (batch-size studies)")
+    ap.add_argument("--verify", type=int, default=8,
+                    help="after the timed region (outside it): replay this many arenas of the rank through the CPU oracle for EVERY step "
+                         "the GPU ran (warm-up + timed) with the same actions and compare the state bit for bit; 0 = off")
     ap.add_argument("--as-rank", type=int, default=None,
                     help="rehearsal (tests): a single process plays rank R of a larger job -- arena offset R * arenas, action seed of rank R")
     return ap.parse_args()
@@ -174,6 +177,82 @@ def cpu_baseline(workload, mode, seconds, variant="walls", starts="overlap"):
                       "through the whole sample (%.1f s); and %d arenas x %d steps on one thread (%.1f s); same workload "
                       "(%s mode, %s, %s starts), oracle/ca_oracle.cpp -O2"
                       % (Am, N, sm, cores, dm, A1, s1, d1, mode, variant, starts)}
+
+
+def verify_against_oracle(env, args, w, p, scn, arena_offset, pool, total_steps, timed_steps):
+    """The parity check of THIS run, on the state the timed region really ran in: `k` arenas of this rank are replayed
+    through the CPU oracle (the checker -- never the thing measured) from the initial scenario through all `total_steps`
+    steps the GPU has executed (warm-up included) with the same action pool, and every state field is compared with the
+    GPU's bit for bit; the collision counters of the timed region too.  Scenario draws, re-goals and ALAN draws are
+    counter-based and keyed by the GLOBAL arena id, so a block of arenas replays on its own."""
+    import numpy as np
+    from collision_avoidance_amd import _lib
+    from oracle import oracle as o
+    from tests import helpers as H
+    t0 = time.perf_counter()
+    A, N = env.A, env.N
+    k = max(1, min(args.verify, A, max(2, 2048 // N)))
+    start = (1234 + 37 * (arena_offset // max(1, A))) % (A - k + 1)
+    orc = H.make_oracle(k, N, scn, p, seed=0, arena_offset=arena_offset + start,
+                        polys=None if args.variant == "walls" else [])
+    threads = max(1, min(k, host_cores()))
+    warm = total_steps - timed_steps
+
+    def advance(first, n):            # steps [first, first + n) of the run
+        if n <= 0:
+            return
+        if args.mode == "step":
+            acts = np.roll(pool[:, start:start + k], -(first % pool.shape[0]), axis=0)    # this block's actions, step `first` first
+            orc.rollout_mt(n - 1, acts, flags=o.F_STATS, n_threads=threads)        # the observation feeds nothing back: only
+            orc.step(acts[(n - 1) % acts.shape[0]], flags=o.F_STATS | o.F_OBS)       # the last step's is computed (and compared)
+        elif args.mode == "orca":
+            orc.rollout_mt(n, None, flags=o.F_STATS, n_threads=threads)
+        else:
+            for _ in range(n):
+                orc.alan_step(flags=o.F_STATS)
+    if args.mode == "alan":
+        from collision_avoidance_amd import alan as _alan
+        orc.alan_configure(_alan.DEFAULT_ACTIONS)
+    advance(0, warm)
+    before = orc.get(o.FLD_ARENA_STATS).copy()
+    advance(warm, timed_steps)
+    names = ["POS_X", "POS_Y", "VEL_X", "VEL_Y", "PREF_X", "PREF_Y", "GOAL_X", "GOAL_Y", "GOAL2_X", "GOAL2_Y", "AGENT_DONE",
+             "ARRIVE_STEP", "STEP_COUNT", "ARENA_DONE", "EPISODE", "REGOAL_COUNT", "NB_COUNT", "OBST_COUNT"]
+    if args.mode == "step":
+        names += ["REWARD", "OBS"]
+    if args.mode == "alan":
+        names += ["ALAN_ACTION", "ALAN_WEIGHTS", "ALAN_TIMES"]
+    mismatch = None
+
+    def bits(a):
+        a = np.ascontiguousarray(a)
+        return a.view({4: np.uint32, 8: np.uint64, 2: np.uint16, 1: np.uint8}[a.dtype.itemsize])
+    for name in names:
+        g = env.get(getattr(_lib, "FLD_" + name))[start:start + k]
+        c = orc.get(getattr(o, "FLD_" + name))
+        if g.shape != c.shape or not np.array_equal(bits(g), bits(c)):
+            bad = np.argwhere(bits(g) != bits(c)) if g.shape == c.shape else []
+            mismatch = "%s: %d of %d entries differ%s" % (name, len(bad), g.size, (
+                "; first at %s: gpu %r oracle %r" % (tuple(bad[0]), g[tuple(bad[0])], c[tuple(bad[0])])) if len(bad) else "")
+            break
+    if mismatch is None:              # the neighbour lists of the last step (entries beyond the count are not defined)
+        gc, gi = env.neighbor_lists()
+        oc, oi = orc.get(o.FLD_NB_COUNT), orc.get(o.FLD_NB_IDX)
+        m = np.arange(oi.shape[2])[None, None, :] < oc[:, :, None]
+        if not np.array_equal(np.where(m, gi[start:start + k], -1), np.where(m, oi, -1)):
+            mismatch = "NB_IDX differs"
+    if mismatch is None:              # the counters of the TIMED region (bench.py resets the GPU's after the warm-up)
+        gs = env.get(_lib.FLD_ARENA_STATS)[start:start + k].astype(np.int64)
+        cs = (orc.get(o.FLD_ARENA_STATS).astype(np.int64) - before.astype(np.int64))
+        for col, what in ((1, "collisions"), (2, "obst_collisions"), (3, "goals_reached"), (4, "obst_overflow")):
+            if not np.array_equal(gs[:, col], cs[:, col]):
+                mismatch = "per-arena %s of the timed region: gpu %s oracle %s" % (what, gs[:, col].tolist(), cs[:, col].tolist())
+                break
+    return {"arenas": k, "first_global_arena": arena_offset + start, "steps": total_steps, "timed_steps": timed_steps,
+            "fields": len(names) + 2, "bit_exact": mismatch is None, "mismatch": mismatch,
+            "seconds": round(time.perf_counter() - t0, 2),
+            "how": "CPU oracle (oracle/ca_oracle.cpp) stepped from the initial scenario with the same action pool; state, lists, "
+                   "reward / observation of the last step and the timed region's per-arena counters compared as bit patterns"}
 
 
 def counters_for(workload, mode, variant, starts, kernels):
@@ -304,6 +383,7 @@ def main():
     ktimes = env.profile_read()
     env.profile(0)
     st = env.stats()
+    steps_run = warm_run + args.steps      # every step this environment has been advanced since its scenario was drawn
     per_step_calls = None
     if not full and not alan_mode and chunk > 1:   # the same ORCA-only workload through one ca_orca_step call per step, for comparison
         torch.cuda.synchronize()
@@ -313,10 +393,16 @@ def main():
             env._call("ca_orca_step", env.h, _lib.F_STATS)
         torch.cuda.synchronize()
         per_step_calls = A * N * n2 / (time.perf_counter() - t1)
+        steps_run += n2
+    verified = None
+    if args.verify > 0:
+        verified = verify_against_oracle(env, args, w, p, scn, arena_offset, pool.cpu().numpy(), steps_run, steps_run - warm_run)
 
     # THE collective of the job: one all_gather of the per-rank record -- statistics, device, and the rank's own time for the
     # timed region in nanoseconds (RCCL over xGMI when N > 1); the job's time is the maximum over the gathered records
-    per_rank_stats, total_stats = cad.gather_stats(st, device=coll_dev, extra={"device": local, "dt_ns": int(dt * 1e9)})
+    per_rank_stats, total_stats = cad.gather_stats(st, device=coll_dev, extra={
+        "device": local, "dt_ns": int(dt * 1e9), "verified": -1 if verified is None else int(verified["bit_exact"]),
+        "verify_arena0": -1 if verified is None else verified["first_global_arena"]})
     dt = max(d["dt_ns"] for d in per_rank_stats) * 1e-9
     if rank == 0:
         agents = A * N
@@ -380,6 +466,10 @@ def main():
                                   "over the live kernel times" % csrc}
             except Exception:
                 valu = None
+        limited_by = None
+        if valu is not None and traffic is not None:
+            hbm_frac = traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            limited_by = "valu-issue" if valu["frac_of_issue_bound_low"][dom] > hbm_frac else "hbm"
         out = {
             "metric": "agent-steps/sec (whole node), %d arenas x %d agents per GPU" % (A, N),
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
@@ -397,14 +487,15 @@ def main():
                        "rollout_chunk": chunk, "steps_per_launch": steps_per_launch, "lanes_per_agent": lanes_per_agent,
                        "sharding": "arenas, %d per GPU" % A},
             "world_size": world,
-            "ranks": [{"rank": r, "device": d["device"], "agent_steps": d["agent_steps"]}
-                      for r, d in enumerate(per_rank_stats)],
+            "ranks": [{"rank": r, "device": d["device"], "agent_steps": d["agent_steps"], "verified": d["verified"],
+                       "verify_arena0": d["verify_arena0"]} for r, d in enumerate(per_rank_stats)],
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_low": traffic_low, "traffic_high": traffic_high,
-                         # what the counters say really limits the kernel: vector-instruction issue (see `valu`:
-                         # frac_of_issue_bound), not HBM -- the HBM fraction above is reported because the metric asks for it
-                         "limited_by": "valu-issue",
+                         # what the COUNTERS of this build say limits the dominant kernel: its vector-issue time (see `valu`)
+                         # against the time its measured HBM traffic needs at the peak; null without a counter profile of
+                         # these sources -- the HBM fraction above is reported because the metric asks for it
+                         "limited_by": limited_by,
                          "algorithmic_bytes_per_agent": kbytes, "kernel_ms": kms, "per_kernel": per_kernel,
                          "traffic_detail": traffic_detail},
             "valu": valu,
@@ -421,6 +512,9 @@ def main():
             "collectives": {"data_path": 0, "job": "one all_gather of the per-rank record (statistics, device, dt)",
                             "timing_barriers": 2 if dist is not None else 0},
         }
+        if verified is not None:      # rank 0's own record + the verdict of every rank (folded into the one all_gather)
+            out["verified"] = dict(verified, bit_exact=all(d["verified"] == 1 for d in per_rank_stats),
+                                   ranks_verified=sum(1 for d in per_rank_stats if d["verified"] == 1))
         if per_step_calls is not None:
             out["orca_per_step_calls"] = {"value": world * per_step_calls, "unit": "agent-steps/s",
                                           "note": "same workload, one ca_orca_step call (= one launch) per step; rank 0's rate x world"}
@@ -431,7 +525,17 @@ def main():
                              (sum(d["agent_steps"] for d in per_rank_stats), world * agents * args.steps))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.mode, args.cpu_seconds, args.variant, args.starts)
+            try:   # the reference's OWN Python loop cannot run on this box (it never travels): quote the committed measurement
+                j = json.load(open(os.path.join(ROOT, "profiles", "r05_reference_python_loop.json")))
+                out["cpu_baseline"]["reference_python_loop"] = {
+                    "label": j["label"], "measured": "in the build container by tools/time_reference_loop.py, NOT on this box",
+                    "cpu": j["cpu"], "cores": j["cores_used"],
+                    "agent_steps_per_s": {r["what"] + " [drawing " + r["drawing"] + "]": round(r["agent_steps_per_s"], 1) for r in j["rows"]}}
+            except Exception:
+                pass
         print(json.dumps(out))
+        if verified is not None and not out["verified"]["bit_exact"]:
+            raise SystemExit("bench.py: --verify FAILED: %s" % [verified["mismatch"]] + str([d["verified"] for d in per_rank_stats]))
     env.close()
     if dist is not None:
         dist.destroy_process_group()

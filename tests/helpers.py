@@ -51,15 +51,18 @@ def make_gpu(A, N, scenario, params, seed=0, arena_offset=0, max_obst_neighbors=
 
 
 def _eq(a, b, what):
-    a, b = np.asarray(a), np.asarray(b)
+    """Bit patterns: +0.0 is not -0.0, a NaN equals only the same NaN."""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape and a.dtype.kind == b.dtype.kind, (what, a.shape, b.shape, a.dtype, b.dtype)
     if a.dtype.kind == "f":
-        ok = np.array_equal(a.view(np.uint32), b.view(np.uint32)) or np.array_equal(a, b, equal_nan=True)
-    else:
-        ok = np.array_equal(a, b)
+        assert a.dtype == b.dtype, (what, a.dtype, b.dtype)
+        u = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+        a, b = a.view(u), b.view(u)
+    ok = np.array_equal(a, b)
     if not ok:
-        bad = np.argwhere(~((a == b) | (np.isnan(a) & np.isnan(b)) if a.dtype.kind == "f" else (a == b)))
+        bad = np.argwhere(a != b)
         first = tuple(bad[0])
-        raise AssertionError("%s differs at %d of %d entries; first %s: gpu=%r oracle=%r"
+        raise AssertionError("%s differs at %d of %d entries; first %s: gpu=%r oracle=%r (bit patterns if float)"
                              % (what, len(bad), a.size, first, a[first], b[first]))
 
 

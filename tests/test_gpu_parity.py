@@ -498,6 +498,48 @@ def test_full_size_properties(name, A, N, nd, K, steps):
     env.close()
 
 
+SETTLED = [("C3-shaped", 64, 64, 5.0, 10, 10000), ("C5-shaped", 8, 512, 5.0, 10, 10000), ("C2-shaped", 256, 16, 1.5, 5, 10000)]
+
+
+@pytest.mark.parametrize("name,A,N,nd,K,steps", SETTLED, ids=[c[0] for c in SETTLED])
+def test_parity_in_the_settled_regime_the_bench_times(name, A, N, nd, K, steps):
+    """bench.py times the crowd AFTER >= 8 000 warm-up steps: contracted, full neighbour lists, ~14 overlapping pairs
+    per arena-step against ~2 in the first few hundred (round 4's one parity bug lived in a regime no short run
+    reached).  The bench's own loop -- the same 16-entry action pool, one full step per entry, statistics on, no
+    reset -- for 10 000 steps on a C3-, C5- and C2-shaped batch, every arena against the oracle bit for bit: state,
+    lists, counters; then full steps with the observation."""
+    from collision_avoidance_amd import _lib
+    nt = min(16, os.cpu_count() or 1)
+    p = scenarios.bench_params(N, nd, K)
+    env = H.make_gpu(A, N, "crowd", p, seed=0, use_torch=False)
+    orc = H.make_oracle(A, N, "crowd", p, seed=0)
+    pool = np.random.RandomState(1234).uniform(-0.5, 0.5, (16, A, N)).astype(np.float32)
+    early = None
+    for s in range(steps):
+        env._call("ca_step_host", env.h, pool[s % 16].ctypes.data, _lib.F_STATS)         # no observation, nothing copied back
+        if s == 599:
+            early = env.stats()["collisions"] / 600.0 / A
+    orc.rollout_mt(steps, pool, flags=o.F_STATS, n_threads=nt)
+    H.assert_state_equal(env, orc, name + " after %d steps of the bench loop (all arenas)" % steps, reward=True)
+    H.assert_stats_equal(env, orc, name)
+    late0 = env.stats()["collisions"]
+    for s in range(steps, steps + 200):                                                   # the regime itself, measured
+        env._call("ca_step_host", env.h, pool[s % 16].ctypes.data, _lib.F_STATS)
+    orc.rollout_mt(200, np.roll(pool, -(steps % 16), axis=0), flags=o.F_STATS, n_threads=nt)
+    late = (env.stats()["collisions"] - late0) / 200.0 / A
+    assert N < 64 or late > 2 * early, (early, late)        # the dense shapes have settled into the contact regime
+    for s in range(steps + 200, steps + 204):                                             # full steps: observation out
+        ob, rew, done, _ = env.step(pool[s % 16], stats=True)
+        orc.step_mt(pool[s % 16], flags=o.F_OBS | o.F_STATS, n_threads=nt)
+    H.assert_state_equal(env, orc, name + " full steps in the settled regime", obs=True, reward=True)
+    H.assert_stats_equal(env, orc, name)
+    gs, es = env.get(_lib.FLD_ARENA_STATS), orc.get(o.FLD_ARENA_STATS)
+    np.testing.assert_array_equal(gs[:, [0, 1, 2, 3, 4, 6, 7]], es[:, [0, 1, 2, 3, 4, 6, 7]])
+    assert env.stats()["agent_steps"] == A * N * (steps + 204) and env.stats()["obst_overflow"] == 0
+    print("%s: overlapping pairs per arena-step %.2f in the first 600 steps, %.2f after %d" % (name, early, late, steps))
+    env.close()
+
+
 def test_processed_obstacle_table_equals_oracle():
     """ca_set_obstacles cuts edges like processObstacles; the vertex table (ids, links, coordinates) is the
     oracle's, so neighbour ids mean the same thing on both sides."""

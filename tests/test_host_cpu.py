@@ -4,7 +4,9 @@ reference's constants.  No compute call is made (there is no GPU here and no CPU
 import ctypes as C
 import os
 import re
+import sys
 
+import numpy as np
 import pytest
 
 from tools import alan_actions
@@ -142,3 +144,55 @@ def test_no_hot_kernel_uses_scratch_memory():
     for want in ("step_kernel<10, 64, 4, true, 1, 16, false>", "step_kernel<10, 64, 4, true, 1, 16, true>"):
         k = [r for r in rows if r["name"].startswith(want)]
         assert k and k[0]["scratch"] == 0 and k[0]["vgpr_spill"] == 0, (want, k)
+
+
+class _FakeGpu(object):
+    """An oracle env behind the few VecCollisionAvoidanceEnv calls bench.verify_against_oracle makes: exercises the checker's
+    own logic (which arenas, which actions at which step, the timed region's counters) without a GPU."""
+
+    def __init__(self, A, N, scn, p, pool, warm, timed, corrupt=False):
+        from tests import helpers as H
+        from oracle import oracle as o
+        self.A, self.N, self.o = A, N, o
+        self.env = H.make_oracle(A, N, scn, p, seed=0)
+        for s in range(warm + timed):
+            if s == warm:
+                self.before = self.env.get(o.FLD_ARENA_STATS).copy()
+            self.env.step(pool[s % len(pool)], flags=o.F_STATS | o.F_OBS)
+        if corrupt:
+            x = self.env.get(o.FLD_POS_X)
+            x[A - 1, N - 1] = np.nextafter(x[A - 1, N - 1], np.float32(100))       # one ulp in one agent of the batch
+            self.env.set(o.FLD_POS_X, x)
+
+    def get(self, field):
+        from collision_avoidance_amd import _lib
+        name = [k for k in dir(_lib) if k.startswith("FLD_") and getattr(_lib, k) == field][0]
+        v = self.env.get(getattr(self.o, name))
+        return (v - self.before) if name == "FLD_ARENA_STATS" else v
+
+    def neighbor_lists(self):
+        return self.env.get(self.o.FLD_NB_COUNT), self.env.get(self.o.FLD_NB_IDX)
+
+
+def test_bench_verify_checker_logic():
+    """bench.py --verify: the replayed block of arenas, the action of every step and the counters of the timed region line
+    up with what the environment ran -- and a single ulp in a single agent is reported."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    A, N, warm, timed = 12, 16, 37, 21
+    w = dict(n_arenas=A, n_agents=N, neighbor_dist=5.0, max_neighbors=10)
+    p = scenarios.bench_params(N, 5.0, 10)
+    pool = np.random.RandomState(5).uniform(-0.5, 0.5, (16, A, N)).astype(np.float32)
+    args = argparse.Namespace(verify=12, mode="step", variant="walls")
+    ok = bench.verify_against_oracle(_FakeGpu(A, N, "crowd", p, pool, warm, timed), args, w, p, "crowd", 0, pool, warm + timed, timed)
+    assert ok["bit_exact"] and ok["arenas"] == 12 and ok["steps"] == warm + timed, ok
+    args.verify = 5            # a block in the middle of the batch
+    ok = bench.verify_against_oracle(_FakeGpu(A, N, "crowd", p, pool, warm, timed), args, w, p, "crowd", 0, pool, warm + timed, timed)
+    assert ok["bit_exact"] and ok["arenas"] == 5 and ok["first_global_arena"] > 0, ok
+    args.verify = 12
+    bad = bench.verify_against_oracle(_FakeGpu(A, N, "crowd", p, pool, warm, timed, corrupt=True), args, w, p, "crowd", 0, pool,
+                                      warm + timed, timed)
+    assert not bad["bit_exact"] and bad["mismatch"].startswith("POS_X: 1 of"), bad
+    off = bench.verify_against_oracle(_FakeGpu(A, N, "crowd", p, pool, warm, timed), args, w, p, "crowd", 0, pool, warm + timed + 1, timed)
+    assert not off["bit_exact"]                                    # one step more or less is a mismatch too
