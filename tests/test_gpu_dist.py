@@ -49,6 +49,14 @@ def test_gloo_ranks_drive_the_hip_library(world, arenas):
     for k in INT_KEYS:
         assert job["stats"][k] == sum(s["stats"][k] for s in singles), (k, job["stats"], [s["stats"] for s in singles])
     assert job["stats"]["goals_reached"] > 0        # the crowd did something in 50 steps
+    # --verify under --gpus N: EVERY rank replayed arenas of its own global range through the oracle and its verdict came
+    # through the one all_gather; the blocks differ by the ranks' arena offsets
+    v = job["verified"]
+    assert v["bit_exact"] and v["ranks_verified"] == world and v["steps"] == STEPS + WARM, v
+    assert [r["verified"] for r in job["ranks"]] == [1] * world
+    a0 = [r["verify_arena0"] for r in job["ranks"]]
+    assert all(r * arenas <= a < (r + 1) * arenas for r, a in enumerate(a0)), a0
+    assert [s["ranks"][0]["verify_arena0"] for s in singles] == a0     # a single process playing rank r checks the same block
     # every rank ran the HIP kernels: the launch geometry is that of its shard; the line names the code that ran
     assert job["launch"] == singles[0]["launch"]
     assert job["src_sha"] == singles[0]["src_sha"] == job["src_sha_on_disk"] != "unknown"
@@ -68,7 +76,8 @@ def test_rccl_carries_the_barriers_and_the_record_in_a_world_of_one():
            "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
     job = _bench([], env, wl)
     assert job["backend"] == "nccl" and job["world_size"] == 1 and job["collectives"]["timing_barriers"] == 2
-    assert job["ranks"] == [{"rank": 0, "device": 0, "agent_steps": 256 * 16 * STEPS}]
+    assert len(job["ranks"]) == 1 and job["ranks"][0]["agent_steps"] == 256 * 16 * STEPS and job["ranks"][0]["device"] == 0
+    assert job["ranks"][0]["verified"] == 1 and job["verified"]["bit_exact"]       # the verdict rode the RCCL all_gather too
     single = _bench([], {}, wl)
     for k in INT_KEYS:
         assert job["stats"][k] == single["stats"][k], (k, job["stats"], single["stats"])
