@@ -1592,6 +1592,53 @@ int ca_debug_set_order(ca_env* e, const int32_t* order) {
     return CA_OK;
 }
 
+/* CA_STAMPS diagnostic build only: the pieces of the dispatch timeline of tools/diag/timeline.py.  ca_debug_clock launches a
+ * one-wave kernel on the handle's stream that writes the device-wide 100 MHz counter at its start and end into slot `slot`
+ * (in-stream fences around a dispatch: the kernel before it has ended, the kernel after it has not begun);
+ * ca_debug_empty launches a kernel of the solve kernel's grid, block and LDS size whose waves only stamp their start and end. */
+__global__ void debug_clock_kernel(unsigned long long* out) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (threadIdx.x == 0) out[0] = t0;
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (threadIdx.x == 0) out[1] = t1;
+}
+__global__ void debug_empty_kernel(unsigned long long* dbg, int waves_per_block) {
+    extern __shared__ float4 smem4[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (threadIdx.x == 4096) smem4[0] = make_float4(0.f, 0.f, 0.f, 0.f);   // (keeps the LDS allocation)
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* r = dbg + ((size_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6)) * 16;
+        r[12] = t0; r[11] = t1;
+    }
+}
+static unsigned long long* g_dbg_clock = nullptr;
+int ca_debug_clock(ca_env* e, int32_t slot) {
+    if (!e || slot < 0 || slot >= 64) return fail(e, CA_EINVAL, "ca_debug_clock: bad argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    if (!g_dbg_clock) HIPCHK(e, hipMalloc((void**)&g_dbg_clock, 64 * 2 * 8));
+    hipLaunchKernelGGL(debug_clock_kernel, dim3(1), dim3(64), 0, e->stream, g_dbg_clock + 2 * slot);
+    return CA_OK;
+}
+int ca_debug_clock_read(ca_env* e, unsigned long long* out, int32_t n_slots) {
+    if (!e || !g_dbg_clock || n_slots > 64) return fail(e, CA_EINVAL, "ca_debug_clock_read: bad argument");
+    HIPCHK(e, download(e, out, g_dbg_clock, (size_t)n_slots * 2 * 8));
+    return CA_OK;
+}
+int ca_debug_empty(ca_env* e) {
+    if (!e || !e->dbg) return fail(e, CA_EINVAL, "ca_debug_empty: not a CA_STAMPS build");
+    HIPCHK(e, hipSetDevice(e->device));
+    ProfScope ps(e, KIND_RESET);   // (timed under "reset_kernels": the step launch in front of it keeps "step_kernel")
+    launch_k(ps, debug_empty_kernel, dim3(e->grid), dim3(e->BS), (size_t)e->lds, e->stream, e->dbg, e->BS / 64);
+    return CA_OK;
+}
+
 /* CA_STAMPS diagnostic build only (not declared in include/ca_env.h): per-wave phase time stamps
  * of the last step kernel, [waves][16] u64. */
 int ca_debug_stamps(ca_env* e, unsigned long long* out, int32_t max_waves, int32_t* n_waves) {

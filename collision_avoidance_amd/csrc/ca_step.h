@@ -633,10 +633,17 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
     CA_STAMP(10);
     __syncthreads();  // all lanes have read red[] and episode[]
     if (active) {
+#if defined(CA_NT_STATE)   // diagnostic (tools/diag/timeline.py): the state leaves through non-temporal stores
+        __builtin_nontemporal_store(ox, &c.orient_x[q]); __builtin_nontemporal_store(oy, &c.orient_y[q]);
+        __builtin_nontemporal_store(pos.x, &c.pos_x[q]); __builtin_nontemporal_store(pos.y, &c.pos_y[q]);
+        __builtin_nontemporal_store(vel.x, &c.vel_x[q]); __builtin_nontemporal_store(vel.y, &c.vel_y[q]);
+        if constexpr (!ALAN) { __builtin_nontemporal_store(pref.x, &c.pref_x[q]); __builtin_nontemporal_store(pref.y, &c.pref_y[q]); }
+#else
         c.orient_x[q] = ox; c.orient_y[q] = oy;
         c.pos_x[q] = pos.x; c.pos_y[q] = pos.y;
         c.vel_x[q] = vel.x; c.vel_y[q] = vel.y;
         if constexpr (!ALAN) { c.pref_x[q] = pref.x; c.pref_y[q] = pref.y; }   // (ALAN: written above)
+#endif
         if (i == 0) {
             unsigned long long* st = c.arena_stats + (size_t)a * ST_STRIDE;
             if (red[1]) st[ST_COLL] += (unsigned)red[1];
