@@ -227,11 +227,11 @@ __device__ __forceinline__ ObstDev load_obst(const ObstDev* __restrict__ t, int 
 #else                // per-CU shader-clock counter (phase shares inside a wave)
 #define CA_STAMP_CLOCK() __builtin_amdgcn_s_memtime()
 #endif
-// CA_STAMPS == 4 (tools/diag/timeline.py): only the wave's FIRST stamp (12: the head of the fused neighbour search) and its LAST
+// CA_STAMPS == 4 (tools/diag/timeline.py) and == 3 (tools/diag/placement.py): only the wave's FIRST stamp (12: the head of the fused neighbour search) and its LAST
 // (11) are taken -- a timeline of wave starts and ends against the dispatch, from a kernel that is otherwise the product's
 #define CA_STAMP(k)                                                                      \
     do {                                                                                 \
-        if (CA_STAMPS != 4 || (k) == 11 || (k) == 12) {                                  \
+        if (CA_STAMPS < 3 || (k) == 11 || (k) == 12) {                                  \
         __builtin_amdgcn_sched_barrier(0);                                               \
         const unsigned long long _t = CA_STAMP_CLOCK();                                  \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                              \

@@ -167,6 +167,9 @@ __device__ __forceinline__ bool lp1_reg(const float4 (&L)[ML], int no, float rad
             tLeft = (left & (tLeft < t)) ? t : tLeft;
             failed |= (par & (num < 0.0f)) | (!par & (tLeft > tRight));
         }
+#ifdef CA_LP1_SCHED_GROUP
+        if constexpr (j % CA_LP1_SCHED_GROUP == CA_LP1_SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+#endif
     });
     if (failed) return false;
     const V2 opt = opt_fn();
@@ -228,6 +231,9 @@ template <int CTRL>
 __device__ __forceinline__ float quad_xor(float v) { return __int_as_float(quad_xor<CTRL>(__float_as_int(v))); }
 
 // (stride: slots per row of the pool -- POOL_SLOTS; 1 for the single-agent table of ca_step.h solve_many_obstacles)
+// (Round 5 built the variant in which every group first walks to ITS next violated line, so that the wave runs the long body
+// max-over-groups times instead of once per position of the union: bit-exact and 4-8 % SLOWER on C2, C3 and C5 -- the walks are
+// chains of dependent LDS reads whose lengths add up over the body executions; profiles/r05_b_simd_balance_and_lp3_walk.txt.)
 __device__ __noinline__ void lp3_coop(float4* pool, int ML, int nslots, float radius, int stride = POOL_SLOTS) {
     const int lane = threadIdx.x & 63, slot = lane >> 2, q = lane & 3;
     float4* hdr = pool + (size_t)(2 * ML - 1) * stride;

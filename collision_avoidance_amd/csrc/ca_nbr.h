@@ -270,22 +270,24 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
 #define CA_CK_MAXN 64    // the largest arena that first tries the composite keys (see below: larger arenas measured slower)
 #endif
     if (K > 0 && !scanned && N <= CA_CK_MAXN) {
-        // Arenas of at most 64 agents: 32-bit composite keys = (fixed-point distance << logP) | candidate index and
+        // Arenas of at most 64 agents: 32-bit composite keys = (distance image << logP) | candidate index and
         // one v_med3_u32 per list slot and candidate -- new[k] = med3(old[k-1], old[k], x) IS the sorted insert,
         // at half the instructions of the 64-bit network (in so small an arena some lane accepts nearly every
-        // candidate, so the shrinking range of the contract never lets a wave skip the network anyway).  The
-        // fixed-point value floor(d2 * 2^(32-logP) / neighbor_dist^2) is only a MONOTONE image of the fp32
-        // distance, so the composite order can differ from the exact (distance, index) order only between
-        // candidates with the same image.  The list therefore keeps one extra slot (the (K+1)-th smallest), and a
-        // lane whose K+1 smallest composites have pairwise different images provably holds the exact list:
-        // strictly increasing images order the first K exactly and put every other candidate behind them.  A
-        // wave in which some lane fails that test (exact fp32 ties, e.g. the symmetric circle world; ~2e-3 of the
-        // waves of a young random crowd) falls through to the exact 64-bit scan below.  (Arenas of 65 .. 256 agents were tried in
-        // round 4 -- fewer bits of image -- and measured 15-25 % slower once the crowd has settled: it packs at exactly the
-        // contact distance 2 R, so the neighbours of an agent in its dense core share their image and most waves scan twice.)
+        // candidate, so the shrinking range of the contract never lets a wave skip the network anyway).
+        // The image is the fp32 BIT PATTERN of the squared distance, counted down from that of neighbor_dist^2
+        // (round 5): 32 - logP bits hold every float of the top 2^(9 - logP) binades below the range -- for 64 agents and a range
+        // of 5 every d2 in [0.125, 25) -- at full resolution, so there the composite order IS the contract's exact (distance, index)
+        // order (equal images = equal distances = index order), and everything nearer than that is clamped to image 0.  Only a
+        // lane with two or more such candidates (agents within 0.35 of each other at radius 0.5: deep overlaps) cannot order
+        // them; a wave in which some lane has them falls through to the exact 64-bit scan below.  (Rounds 2-4 used a fixed-point
+        // image floor(d2 * 2^26 / 25): a settled crowd packs at exactly the contact distance, the neighbours of an agent in a
+        // dense core differ by a few ulps of d2 = 1 -- less than that image resolves -- and every fifth wave scanned twice:
+        // profiles/r05_c_exact_composite_keys.txt.)
         const float rangeSq0 = sqr(p.neighbor_dist);
         const unsigned lowmask = (unsigned)(P - 1);
-        const float fx_scale = 0.999f * (float)(1u << (31 - p.logP)) * 2.0f / rangeSq0;  // image < 2^(32-logP) - 1
+        const unsigned top = __float_as_uint(rangeSq0);                  // a passing candidate's bits lie below it
+        const unsigned span = 0xFFFFFFFFu >> p.logP;                     // images 0 .. span - 2 (the composite never is ~0)
+        const unsigned u0 = top >= span ? top - span + 1u : 0u;          // bit patterns up to u0 share image 0
         unsigned ck[KMAX + 1];
 #pragma unroll
         for (int k = 0; k <= KMAX; ++k) ck[k] = (k < kofs) ? 0u : 0xFFFFFFFFu;
@@ -295,21 +297,20 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
             if (j + 1 < N) o_next = mk(s_px[lbase + j + 1], s_py[lbase + j + 1]);
             const float dsq = absSq(pos - o);
             const bool pass = active && j != i && dsq < rangeSq0;
-            const unsigned c = pass ? (((unsigned)(dsq * fx_scale) << p.logP) | (unsigned)j) : 0xFFFFFFFFu;
+            const unsigned u = __float_as_uint(dsq);
+            const unsigned c = pass ? ((((u > u0 ? u : u0) - u0) << p.logP) | (unsigned)j) : 0xFFFFFFFFu;
 #pragma unroll
             for (int k = KMAX; k >= 1; --k) ck[k] = umed3(ck[k - 1], ck[k], c);
             ck[0] = ck[0] < c ? ck[0] : c;
         }
-        bool near_tie = false;
         int cnt = 0;
+        bool clamped_pair = false;   // (the list is ascending: two clamped candidates, if there are any, are its first two entries)
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
-            if (k >= kofs) {
-                if (ck[k] != 0xFFFFFFFFu) ++cnt;
-                if (ck[k + 1] != 0xFFFFFFFFu && ((ck[k] ^ ck[k + 1]) <= lowmask)) near_tie = true;
-            }
+            if (k >= kofs && ck[k] != 0xFFFFFFFFu) ++cnt;
+            if (k == kofs) clamped_pair = ck[k + 1] <= lowmask;
         }
-        if (__builtin_amdgcn_ballot_w64(near_tie) == 0ull) {  // wave-uniform
+        if (__builtin_amdgcn_ballot_w64(clamped_pair) == 0ull) {  // wave-uniform
             ncnt = cnt;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)  // hand the indices over in the key array the store below reads

@@ -361,13 +361,17 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
 
         // ---- the lists are state (the reference's reset() observes with the lists of the last doStep) ----
         if (active && write_lists) {
-            if (q == 0) p.counts[gq] = (unsigned short)(ncnt | (ocnt << 8));
+            // (indices behind an opaque move: the K + S store addresses are formed per step -- hoisted out of the T-step loop they
+            // are a dozen 64-bit values that the 512-lane shapes spill and reload every step)
+            int a_l = a, i_l = i;
+            asm volatile("" : "+v"(a_l), "+v"(i_l));
+            if (q == 0) p.counts[a_l * N + i_l] = (unsigned short)(ncnt | (ocnt << 8));
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
-                if ((k & 3) == q && k < K) st_idx_t<false>(p.nb_idx, ((size_t)a * K + k) * N + i, key_index(nkey[k]));
+                if ((k & 3) == q && k < K) st_idx_t<false>(p.nb_idx, ((size_t)a_l * K + k) * N + i_l, key_index(nkey[k]));
 #pragma unroll
             for (int k = 0; k < SQ; ++k)
-                if ((k & 3) == q && k < S) p.obst_idx[((size_t)a * S + k) * N + i] = (unsigned short)key_index(okey[k]);
+                if ((k & 3) == q && k < S) p.obst_idx[((size_t)a_l * S + k) * N + i_l] = (unsigned short)key_index(okey[k]);
         }
 
 #if !defined(CA_STAMPS) || CA_STAMPS != 3
@@ -521,19 +525,23 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
                 if (c.done_mode == 1) hit = hit && (done == 0);
             }
             if (hit) {
+                // (the element index behind an opaque move: the addresses of these rare stores are formed here, per event --
+                // hoisted out of the T-step loop they are nine 64-bit values carried, and at 512 lanes spilled, through every step)
+                int gq_e = gq;
+                asm volatile("" : "+v"(gq_e));
                 if (c.done_mode == 2) {
                     double u0, u1;
                     rng2(c.seed, c.arena_offset + a, i, RNG_REGOAL, (uint32_t)rc, &u0, &u1);
                     gx = uniform64((double)c.goal_x0, (double)c.goal_x1, u0);
                     gy = uniform64((double)c.goal_y0, (double)c.goal_y1, u1);
                     rc += 1;
-                    if (q == 0) c.regoal_count[gq] = rc;
+                    if (q == 0) c.regoal_count[gq_e] = rc;
                 } else {
                     done = 1;
-                    gx = c.goal2_x[gq]; gy = c.goal2_y[gq];
-                    if (q == 0) { c.arrive_step[gq] = steps; c.agent_done[gq] = 1; }
+                    gx = c.goal2_x[gq_e]; gy = c.goal2_y[gq_e];
+                    if (q == 0) { c.arrive_step[gq_e] = steps; c.agent_done[gq_e] = 1; }
                 }
-                if (q == 0) { c.goal_x[gq] = gx; c.goal_y[gq] = gy; }
+                if (q == 0) { c.goal_x[gq_e] = gx; c.goal_y[gq_e] = gy; }
                 goal_changed = true;
                 if (q == 0) atomicAdd(&red[3], 1);
             }
@@ -554,7 +562,9 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
             pos = mk((float)uniform64((double)c.spawn_x0, (double)c.spawn_x1, u0),
                      (float)uniform64((double)c.spawn_y0, (double)c.spawn_y1, u1));
             done = 0;
-            if (q == 0) c.agent_done[gq] = 0;
+            int gq_r = gq;
+            asm volatile("" : "+v"(gq_r));
+            if (q == 0) c.agent_done[gq_r] = 0;
             double dx, dy;
             pref_dir64(pos.x, pos.y, gx, gy, &dx, &dy);
             pref = mk((float)dx, (float)dy);
@@ -568,7 +578,9 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
                 double r = s_rew[tid];
                 const int w = P < 64 ? P : 64;
                 for (int off = w >> 1; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
-                const int la2 = tid >> p.logP, i2 = tid & (P - 1), a2 = p.a0 + (int)blockIdx.x * apb + la2;
+                int tid2 = tid;   // (opaque: the addresses below are derived per step, not hoisted out of the T-step loop and
+                asm volatile("" : "+v"(tid2));   // carried -- spilled, at 512 lanes -- through every step of it)
+                const int la2 = tid2 >> p.logP, i2 = tid2 & (P - 1), a2 = p.a0 + (int)blockIdx.x * apb + la2;
                 if (a2 < p.a1 && i2 < N && (i2 & 63) == 0 && !((p.flags & 16u) != 0 && p.arena_done[a2] != 0))
                     atomicAdd(reinterpret_cast<double*>(&c.arena_stats[(size_t)a2 * ST_STRIDE + ST_SUMREW]), r);
             }

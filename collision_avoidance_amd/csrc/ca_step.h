@@ -284,7 +284,7 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
 #if defined(CA_STAMPS) && CA_STAMPS == 3
                 if ((tid & 63) == 0 && p.dbg) p.dbg[((size_t)blockIdx.x * (BS / 64) + (tid >> 6)) * 16 + 4] += 1 + ((unsigned long long)__popcll(m) << 32);
 #endif
-                if (!m) break;
+                if (__builtin_expect(!m, 1)) break;
                 const int rank = __popcll(m & below);
                 const bool mine = need && rank < POOL_SLOTS;
                 if (mine) {
@@ -322,9 +322,13 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
                 const int cnts_o = act_o ? (int)p.counts[a_o * N + i_o] : 0;
                 bool need_o = (cnts_o >> 8) > ST;
                 const unsigned long long below_o = (1ull << (tid_o & 63)) - 1ull;
+                // (the constants of the call below, read again behind opaque moves: shared with the hot path's copies they would
+                // be carried through the whole solve in vector registers for the sake of this rare stage -- and spilled)
+                float rad_o = p.radius, tho_o = p.time_horizon_obst, th_o = p.time_horizon, dt_o = p.time_step, ms_o = p.max_speed;
+                asm volatile("" : "+s"(rad_o), "+s"(tho_o), "+s"(th_o), "+s"(dt_o), "+s"(ms_o));
                 while (true) {
                     const unsigned long long om = __ballot(need_o);
-                    if (!om) break;
+                    if (__builtin_expect(!om, 1)) break;     // (rare: tells the register allocator that this loop is cold)
                     const int rank = __popcll(om & below_o);
                     const bool mine = need_o && rank < GX;
                     if (mine) {
@@ -332,8 +336,8 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
                         solve_many_obstacles<CA_NBW16(BS), GX>(pool + rank, MLX, tab_o, obst_idx_s + (size_t)a_o * S * N + i_o,
                                                                (const char*)nb_idx_s + ((size_t)a_o * K * N + i_o) * (CA_NBW16(BS) ? 2 : 1), N,
                                                                cnts_o >> 8, cnts_o & 0xFF, s_px + (tid_o - i_o), BS,
-                                                               mk(s_px[tid_o], s_py[tid_o]), mk(s_vx[tid_o], s_vy[tid_o]), opt_fn(), p.radius,
-                                                               1.0f / p.time_horizon_obst, 1.0f / p.time_horizon, 1.0f / p.time_step, p.max_speed);
+                                                               mk(s_px[tid_o], s_py[tid_o]), mk(s_vx[tid_o], s_vy[tid_o]), opt_fn(), rad_o,
+                                                               1.0f / tho_o, 1.0f / th_o, 1.0f / dt_o, ms_o);
                     }
                     wave_lds_sync();
                     const int waiting = __popcll(om);
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
                         lp3 = ((hz >> 16) & 0xFF) < (hz & 0xFF);
                     }
                     if (__ballot(lp3) != 0ull) {   // LP2 failed somewhere: LP3 on the same tables, four lanes each (a table whose LP2
-                        lp3_coop(pool, MLX, nt, p.max_speed, GX);   // succeeded has begin = n: untouched)
+                        lp3_coop(pool, MLX, nt, ms_o, GX);   // succeeded has begin = n: untouched)
                         wave_lds_sync();
                     }
                     if (mine) { const float4 h = pool[(2 * MLX - 1) * GX + rank]; nv = mk(h.x, h.y); need_o = false; }

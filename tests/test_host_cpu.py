@@ -135,15 +135,23 @@ def test_no_hot_kernel_uses_scratch_memory():
         assert any(n.startswith(want) for n in names), want
     bad = kr.spilling(rows)
     assert not bad, [(r["name"], r["scratch"], r["vgpr_spill"]) for r in bad]
-    # the kernel the reference env's OWN world selects (doorway, K = 5, obstacle lists of up to 16: env.py:26-44, 117-122)
-    # is not among the exemptions: no scratch at all
-    own = [r for r in rows if r["name"].startswith("step_kernel<5, 64, 4, true, 1, 16, false>")]
-    assert own and own[0]["scratch"] == 0 and own[0]["vgpr_spill"] == 0, own
-    # ... nor are the kernels that large batches of the reference's ALAN worlds select (congested, deadlock, blocks: K = 10, up to
-    # 64 agents, ALAN:195-208, 359-372, 418-455), with and without the bandit inside the launch
-    for want in ("step_kernel<10, 64, 4, true, 1, 16, false>", "step_kernel<10, 64, 4, true, 1, 16, true>"):
-        k = [r for r in rows if r["name"].startswith(want)]
-        assert k and k[0]["scratch"] == 0 and k[0]["vgpr_spill"] == 0, (want, k)
+    # EVERY instantiation pick_variant (ca_env.hip) can select for K <= 10 -- lane kernels with register lines and obstacle
+    # lists of 4 or 16 at every workgroup size, with and without the ALAN bandit; the four-lanes kernel in all its shapes; the
+    # two-lanes kernel -- is present and has no scratch at all (round 4 exempted the multi-wave K = 10 / S = 16 shapes:
+    # 32 B, 40 spilled registers; the reference's "deadlock" world with more than 64 agents selects them, ALAN:418-455)
+    want = ["step_kernel<%d, %d, 4, true, 1, %d, false>" % (k, bs, sm) for k in (5, 10) for bs in (64, 128, 256, 512, 1024) for sm in (4, 16)]
+    want += ["step_kernel<%d, %d, 4, true, 1, %d, true>" % (k, bs, sm) for k in (5, 10) for bs in (64, 128) for sm in (4, 16)]
+    want += ["step_kernel<%d, %d, 4, true, 2, 4, false>" % (k, bs) for k in (5, 10) for bs in (256, 512)]
+    want += ["quad_kernel<%d, %d, %d, %s>" % (k, bs, sq, al) for k in (5, 10) for bs in (64, 128, 256, 512) for sq in (4, 16) for al in ("false", "true")]
+    want += ["pair_kernel<10, 256>", "pair_kernel<10, 512>", "obs_kernel<256"]
+    for w_ in want:
+        k = [r for r in rows if r["name"].startswith(w_)]
+        assert k, w_
+        assert all(r["scratch"] == 0 and r["vgpr_spill"] == 0 for r in k), (w_, [(r["scratch"], r["vgpr_spill"]) for r in k])
+    # the only kernels with a scratch segment are the LDS-line-table ones (K > 10, or a many-edge world in a batch small enough
+    # to be resident with the table: LP3's projected lines are a private array there by design)
+    assert all(re.match(r"step_kernel<\d+, \d+, 0, ", r["name"]) for r in rows if r["scratch"] and any(h in r["name"] for h in kr.HOT)), \
+        [(r["name"], r["scratch"]) for r in rows if r["scratch"]]
 
 
 class _FakeGpu(object):

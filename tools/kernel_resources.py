@@ -21,7 +21,7 @@ from collision_avoidance_amd import build as b  # noqa: E402
 
 OUT = os.path.join(ROOT, "build", "isa")
 ASM = os.path.join(OUT, "ca_env-hip-amdgcn-amd-amdhsa-gfx950.s")
-HOT = ("step_kernel", "quad_kernel", "obs_kernel", "nbr_kernel")   # kernels that must not spill
+HOT = ("step_kernel", "quad_kernel", "pair_kernel", "obs_kernel", "nbr_kernel")   # kernels that must not spill
 
 
 def compile_asm(extra=()):
@@ -67,12 +67,11 @@ def parse(asm_path=ASM):
 def by_design(name):
     """The LDS-line-table variant step_kernel<K, BS, 0, *> keeps LP3's projected lines in a private array (ca_lp.h lp3:
     only the few lanes whose LP2 is infeasible touch it); every other hot kernel must run without scratch memory."""
-    # ... and the K = 10 register-line kernel with obstacle lists of 16 (the world "congested", ALAN:195-208): the stage that
-    # solves an agent with more than four obstacle neighbours apart costs it two of its 14 line slots (32-48 B against the
-    # 448 B of the LDS-table kernel it replaces there); the K = 5 kernel of the reference env's own world has none
-    return re.match(r"step_kernel<\d+, \d+, 0, (true|false)(, \w+)*>", name) is not None or \
-        re.match(r"step_kernel<10, \d+, 4, true, 1, 16(, \w+)*>", name) is not None or \
-        name.startswith("quad_kernel<10, 512, 16")   # instantiated for the launch switch, never selected (ca_create: 256 lanes at most)
+    # (Rounds 3-4 also exempted the K = 10 register-line kernels of two and more waves with obstacle lists of 16 -- two of their
+    # 14 line slots lived in scratch -- and quad_kernel<10, 512, 16>.  Round 5: the register allocator took the two rare stages'
+    # `while (true)` loops for hot and the fully unrolled LP2 for cold; with the loops marked unlikely and the rare stages' constants
+    # and addresses formed where they are used, EVERY instantiation that pick_variant can select for K <= 10 has ScratchSize 0.)
+    return re.match(r"step_kernel<\d+, \d+, 0, (true|false)(, \w+)*>", name) is not None
 
 
 def spilling(rows):

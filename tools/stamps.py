@@ -13,10 +13,14 @@ import numpy as np
 
 from collision_avoidance_amd import build as b
 
-out = os.path.join(ROOT, "gpurun_out", "libcaenv_stamps.so")
-os.makedirs(os.path.dirname(out), exist_ok=True)
 RT = len(sys.argv) > 3 and sys.argv[3] == "rt"   # wall-clock stamps (10 ns ticks) for wave timelines
-subprocess.check_call([b.hipcc()] + b.HIPCC_FLAGS + ["-DCA_STAMPS=%d" % (2 if RT else 1), "-o", out, b.SOURCES[0]])
+# variants/ is git-ignored but travels to the GPU box: `python tools/stamps.py build` here spends no GPU time on the compiler
+out = os.path.join(ROOT, "variants", "libcaenv_stamps%d.so" % (2 if RT else 1))
+os.makedirs(os.path.dirname(out), exist_ok=True)
+if not os.path.exists(out) or any(os.path.getmtime(f) > os.path.getmtime(out) for f in b.SOURCES):
+    subprocess.check_call([b.hipcc()] + b.HIPCC_FLAGS + ["-DCA_STAMPS=%d" % (2 if RT else 1), "-o", out, b.SOURCES[0]])
+if len(sys.argv) > 1 and sys.argv[1] == "build":
+    raise SystemExit(0)
 b.LIB_PATH = out  # the loader reads this
 from collision_avoidance_amd import _lib, scenarios
 from collision_avoidance_amd.vec_env import VecCollisionAvoidanceEnv
