@@ -23,7 +23,8 @@ EXPORTS = ("ca_create", "ca_destroy", "ca_last_error", "ca_set_stream", "ca_set_
            "ca_get", "ca_field_ptr", "ca_bind_obs", "ca_reset", "ca_step", "ca_step_host", "ca_orca_step", "ca_observe", "ca_rollout",
            "ca_get_stats", "ca_reset_stats", "ca_sync", "ca_debug_math", "ca_profile", "ca_profile_read", "ca_launch_info",
            "ca_alan_configure", "ca_alan_step", "ca_alan_rollout", "ca_reset_masked", "ca_get_obstacles",
-           "ca_set_obstacles_per_arena", "ca_get_obstacles_arena", "ca_solver_info", "ca_source_sha")
+           "ca_set_obstacles_per_arena", "ca_get_obstacles_arena", "ca_solver_info", "ca_source_sha", "ca_host_alloc", "ca_host_free",
+           "ca_step_packed")
 
 
 class Config(C.Structure):
@@ -87,6 +88,9 @@ def load():
     L.ca_reset_masked.argtypes = [vp, vp, i32, u32]
     L.ca_step.argtypes = [vp, vp, u32]
     L.ca_step_host.argtypes = [vp, vp, u32]
+    L.ca_step_packed.argtypes = [vp, vp, u32, vp, sz]
+    L.ca_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.ca_host_free.argtypes = [vp, vp]
     L.ca_orca_step.argtypes = [vp, u32]
     L.ca_observe.argtypes = [vp]
     L.ca_rollout.argtypes = [vp, i32, u32]

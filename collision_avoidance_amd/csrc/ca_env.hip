@@ -42,6 +42,9 @@ struct ca_env {
     unsigned long long* arena_steps = nullptr;  // [A] steps each arena was advanced, counted by the solve kernels
     float* obs = nullptr;
     bool obs_external = false;
+    // what a step hands back -- observation | reward | arena_done | step_count -- lies in ONE device allocation in this order, so
+    // that the host-array form of a step (ca_step_packed) fetches all of it with one copy (obs points elsewhere after ca_bind_obs)
+    float* slab = nullptr;
     unsigned long long* dbg = nullptr;  // CA_STAMPS diagnostic build only
     unsigned long long* dbg_obs = nullptr;
     float *tmp_x = nullptr, *tmp_y = nullptr;  // staging for explicit reset positions / host actions
@@ -53,6 +56,7 @@ struct ca_env {
     bool alan_fused = false;      // ca_alan_step / ca_alan_rollout run as ONE launch of the four-lanes kernel
     bool alan_lane = false;       // ca_alan_step runs as ONE launch of the register-line lane kernel (its ALAN instantiation)   // the bandit's arguments for the four-lanes kernel (ca_common.h)
     int* mask_buf = nullptr;  // staging for ca_reset_masked's host mask
+    std::vector<std::pair<void*, size_t>> host_allocs;   // page-locked host buffers handed out by ca_host_alloc (freed by ca_host_free / ca_destroy)
     int n_actions = 0;
     double act_c[CA_ALAN_MAX_ACTIONS], act_s[CA_ALAN_MAX_ACTIONS];
     double alan_temp = 0.2, alan_window = 2.0, alan_dt = 1.0 / 60.0;
@@ -66,6 +70,9 @@ struct ca_env {
     bool obs_dense_on = false;
     bool lists_trusted = true;   // the neighbour lists in memory were written by the kernels (not by the caller through ca_set)
     int LS = 1, apb = 1, linv = 65536, dense = 0;   // lanes per arena, arenas per workgroup, ceil(2^16 / LS), packed back to back (ca_common.h StepArgs)
+    // diagnostic environment switches, read ONCE by ca_create (a handle never changes behaviour because the environment did):
+    // -1 = unset, else the first character's digit
+    struct { int reg_lines = -1, nbr_help = -1, pair = -1, pair_min = 129, alan_fused = -1; } sw;
     int BSn = 64, grid_n = 1;  // the neighbour kernel's own workgroup size
     bool fuse_nbr = true;       // neighbour search at the head of the solve kernel (default) or as its own launch
     int ST = 0, KT = 16;  // solve-kernel variant: ST > 0 = register lines with ST obstacle slots; KT = KMAX
@@ -159,7 +166,7 @@ static FieldInfo field_info(ca_env* e, int f) {
         case CA_FLD_GOAL_Y: return {e->goal_y, an * 8, true};
         case CA_FLD_GOAL2_X: return {e->goal2_x, an * 8, true};
         case CA_FLD_GOAL2_Y: return {e->goal2_y, an * 8, true};
-        case CA_FLD_REWARD: return {e->reward, an * 4, false};
+        case CA_FLD_REWARD: return {e->reward, an * 4, true};   // (writable for set_state: a frozen arena keeps its last reward)
         case CA_FLD_AGENT_DONE: return {e->agent_done, an * 4, true};
         case CA_FLD_ARRIVE_STEP: return {e->arrive_step, an * 4, true};
         // packed in device memory; the ABI shows them as i32 (ca_get / ca_set convert, ca_field_ptr refuses)
@@ -174,7 +181,7 @@ static FieldInfo field_info(ca_env* e, int f) {
         case CA_FLD_REGOAL_COUNT: return {e->regoal_count, an * 4, true};
         case CA_FLD_ALAN_WEIGHTS: return {e->alan_w, an * 8 * (size_t)e->n_actions, true};
         case CA_FLD_ALAN_TIMES: return {e->alan_t, an * 8 * (size_t)e->n_actions, true};
-        case CA_FLD_ALAN_ACTION: return {e->alan_action, an * 4, false};
+        case CA_FLD_ALAN_ACTION: return {e->alan_action, an * 4, true};   // (writable for set_state: a frozen arena keeps its last action)
         case CA_FLD_ARENA_STATS: return {e->arena_stats, A * ST_STRIDE * 8, false};
         default: return {nullptr, 0, false};
     }
@@ -561,8 +568,8 @@ static size_t lds_static_bytes(const ca_env* e) {
 // than four in range).  Called by ca_create (no table yet) and again whenever tables are installed: every variant computes
 // the same bits, so a handle may change variant between steps.
 static void pick_variant(ca_env* e) {
-    const char* v = getenv("CA_REG_LINES");  // diagnostic switch: 0 forces the LDS line table, 1 the register lines wherever they exist
-    const bool allow = !(v && v[0] == '0'), force = v && v[0] == '1';
+    // (CA_REG_LINES, latched by ca_create: 0 forces the LDS line table, 1 the register lines wherever they exist)
+    const bool allow = e->sw.reg_lines != 0, force = e->sw.reg_lines == 1;
     e->KT = e->K <= 5 ? 5 : (e->K <= 10 ? 10 : 16);
     bool table_fits;
     {
@@ -590,30 +597,37 @@ static void pick_variant(ca_env* e) {
     else { e->ST = 0; e->SMX = 16; }
     e->lds = step_lds_bytes(e->BS, e->K, e->S, e->ST, e->KT);
     {   // helper lanes for the uniform-grid neighbour scan: arenas of 192 .. 512 agents on the register-line kernel
-        const char* h = getenv("CA_NBR_HELP");  // diagnostic switch: 0 = none
-        e->help = !(h && h[0] == '0') && e->fuse_nbr && e->ST > 0 && e->SMX == 4 && (e->BS == 256 || e->BS == 512) &&
+        e->help = e->sw.nbr_help != 0 && e->fuse_nbr   /* (CA_NBR_HELP=0: none) */ && e->ST > 0 && e->SMX == 4 && (e->BS == 256 || e->BS == 512) &&
                   e->cfg.n_agents >= 192 && e->K > 0;
     }
     {   // two lanes per agent for the whole step (ca_pair.h) where the helper lanes were: a 512-agent arena is 8 waves of one
         // lane per agent on its CU -- two per SIMD, each a long dependent chain; 16 waves with half the chain each fill it
-        const char* pv = getenv("CA_PAIR");  // diagnostic switch: 0 = the lane kernel (with helper lanes in the scan from 192 agents)
-        const char* pm = getenv("CA_PAIR_MIN");  // diagnostic: smallest arena that takes it
-        const int pair_min = pm ? atoi(pm) : 129;   // (arenas of 65 .. 128 agents -- two waves -- measured faster on the lane kernel: ca_pair.h)
-        e->pair = !(pv && pv[0] == '0') && e->fuse_nbr && e->ST > 0 && e->SMX == 4 && (e->BS == 256 || e->BS == 512) &&
+        // (CA_PAIR=0: the lane kernel, with helper lanes in the scan from 192 agents; CA_PAIR_MIN: smallest arena that takes it --
+        // arenas of 65 .. 128 agents, two waves, measured faster on the lane kernel: ca_pair.h)
+        const int pair_min = e->sw.pair_min;
+        e->pair = e->sw.pair != 0 && e->fuse_nbr && e->ST > 0 && e->SMX == 4 && (e->BS == 256 || e->BS == 512) &&
                   e->cfg.n_agents >= pair_min && e->K > 0;
         e->lds_p = pair_lds_bytes(e->BS, e->KT);
     }
 }
 
-// the dynamic-LDS limits of the kernels pick_variant chose
+// the dynamic-LDS limits of the kernels pick_variant chose -- and, for BOTH callers (ca_create, and install_tables whenever a
+// world is installed and the variant may change), the check that the chosen kernel fits the CU's 160 KiB: the lane kernels by
+// their dynamic part + the statically declared arrays of the fused neighbour search, the two-lanes kernel by what the
+// compiled kernel itself reports (hipFuncGetAttributes).  hipErrorInvalidValue = does not fit (the callers turn it into CA_ERANGE).
+static const size_t LDS_PER_CU = 160 * 1024;
 static hipError_t apply_variant_attributes(ca_env* e) {
     hipError_t r = hipSuccess;
+    if (!e->pair && e->lds + lds_static_bytes(e) > LDS_PER_CU) return hipErrorInvalidValue;
     if (r == hipSuccess && e->pair) {
         const void* f = e->KT == 5 ? (e->BS == 256 ? reinterpret_cast<const void*>(&pair_kernel<5, 256>)
                                                    : reinterpret_cast<const void*>(&pair_kernel<5, 512>))
                                    : (e->BS == 256 ? reinterpret_cast<const void*>(&pair_kernel<10, 256>)
                                                    : reinterpret_cast<const void*>(&pair_kernel<10, 512>));
-        r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_p);
+        hipFuncAttributes fa;
+        r = hipFuncGetAttributes(&fa, f);
+        if (r == hipSuccess && fa.sharedSizeBytes + e->lds_p > LDS_PER_CU) return hipErrorInvalidValue;
+        if (r == hipSuccess) r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_p);
     }
     if (r == hipSuccess && e->help && e->lds > 48 * 1024) {
         const void* f = e->KT == 5 ? (e->BS == 256 ? reinterpret_cast<const void*>(&step_kernel<5, 256, 4, true, 2>)
@@ -639,8 +653,7 @@ static int alan_pick(ca_env* e) {
     e->alan_fused = e->alan_lane = false;
     if (e->n_actions <= 0) return CA_OK;
     const size_t lq = quad_lds_bytes(e->BSq, e->KT, e->SQ, e->n_actions);
-    const char* fv = getenv("CA_ALAN_FUSED");   // diagnostic switch: 0 = the three-launch form everywhere
-    const bool on = !(fv && fv[0] == '0');
+    const bool on = e->sw.alan_fused != 0;   // (CA_ALAN_FUSED=0: the three-launch form everywhere)
     e->alan_fused = on && (e->quad || e->quad_roll) && lq <= 64 * 1024;
     e->alan_lane = on && !e->quad && e->fuse_nbr && !e->help && !e->pair && e->BS <= 128 && e->K <= 10 &&
                    e->n_actions <= (e->ST > 0 ? 4 + e->KT : 2 * (e->K + e->S));
@@ -666,6 +679,20 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         return fail(nullptr, CA_ERANGE, "ca_create: max_obst_neighbors=%d out of range 1..%d",
                     cfg->max_obst_neighbors, CA_MAX_OBST_NEIGHBORS);
     if (cfg->done_mode < 0 || cfg->done_mode > 2) return fail(nullptr, CA_EINVAL, "ca_create: bad done_mode");
+    {   // the supported magnitudes (include/ca_env.h "Units and magnitudes"): the kernels' division and square root run without
+        // their range-scaling instructions (ca_math.h) -- exact for worlds of O(1) units, not for metres-as-nanometres
+        const struct { const char* name; float v, lo, hi; } rng[] = {
+            {"time_step", cfg->time_step, CA_MIN_TIME_STEP, CA_MAX_TIME_STEP}, {"neighbor_dist", cfg->neighbor_dist, CA_MIN_LENGTH, CA_MAX_LENGTH},
+            {"time_horizon", cfg->time_horizon, CA_MIN_LENGTH, CA_MAX_LENGTH}, {"time_horizon_obst", cfg->time_horizon_obst, CA_MIN_LENGTH, CA_MAX_LENGTH},
+            {"radius", cfg->radius, CA_MIN_LENGTH, CA_MAX_LENGTH}, {"max_speed", cfg->max_speed, CA_MIN_LENGTH, CA_MAX_LENGTH}};
+        for (const auto& q : rng)
+            if (!(q.v >= q.lo && q.v <= q.hi))   // (also false for NaN)
+                return fail(nullptr, CA_ERANGE, "ca_create: %s=%g outside the supported range [%g, %g]", q.name, (double)q.v, (double)q.lo, (double)q.hi);
+        const float box[] = {cfg->spawn_x0, cfg->spawn_x1, cfg->spawn_y0, cfg->spawn_y1, cfg->goal_x0, cfg->goal_x1, cfg->goal_y0, cfg->goal_y1,
+                             cfg->done_x_thresh};
+        for (float v : box)
+            if (!(fabsf(v) <= CA_MAX_COORD)) return fail(nullptr, CA_ERANGE, "ca_create: a spawn / goal box coordinate (%g) is beyond %g or not a number", (double)v, (double)CA_MAX_COORD);
+    }
     if ((size_t)cfg->n_arenas * cfg->n_agents > (size_t)1 << 30)
         return fail(nullptr, CA_ERANGE, "ca_create: more than 2^30 agents on one handle");
     int ndev = 0;
@@ -679,6 +706,13 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     if (r == hipSuccess) {
         if (stream) e->stream = (hipStream_t)stream;
         else { r = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking); e->own_stream = true; }
+    }
+    {   // the diagnostic switches, once
+        auto digit = [](const char* name) { const char* v = getenv(name); return (v && v[0] >= '0' && v[0] <= '9') ? v[0] - '0' : -1; };
+        e->sw.reg_lines = digit("CA_REG_LINES"); e->sw.nbr_help = digit("CA_NBR_HELP"); e->sw.pair = digit("CA_PAIR");
+        e->sw.alan_fused = digit("CA_ALAN_FUSED");
+        const char* pm = getenv("CA_PAIR_MIN");
+        if (pm && atoi(pm) > 0) e->sw.pair_min = atoi(pm);
     }
     // launch geometry: P lanes per arena (power of two >= N), one or more whole arenas per block
     int P = 1, logP = 0;
@@ -742,7 +776,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         e->grid_q = (cfg->n_arenas + apbq - 1) / apbq;
         e->lds_q = quad_lds_bytes(e->BSq, e->KT, e->SQ);
     }
-    if (e->lds + lds_static_bytes(e) > 160 * 1024) {
+    if (!e->pair && e->lds + lds_static_bytes(e) > LDS_PER_CU) {
         fail(nullptr, CA_ERANGE, "ca_create: the solve kernel would need %zu B of LDS (> 160 KiB) for n_agents=%d, "
              "max_neighbors=%d, max_obst_neighbors=%d: arenas above 256 agents need max_neighbors <= 10 "
              "(register-line variant)", e->lds + lds_static_bytes(e), cfg->n_agents, e->K, e->S);
@@ -752,7 +786,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     }
     host_tables(e);
     const size_t an = AN(e), A = cfg->n_arenas;
-    float** f32s[] = {&e->pos_x, &e->pos_y, &e->vel_x, &e->vel_y, &e->pref_x, &e->pref_y, &e->reward,
+    float** f32s[] = {&e->pos_x, &e->pos_y, &e->vel_x, &e->vel_y, &e->pref_x, &e->pref_y,
                       &e->tmp_x, &e->tmp_y, &e->orient_x, &e->orient_y};
     for (auto p : f32s) if (r == hipSuccess) r = dalloc(e, p, an);
     double** f64s[] = {&e->goal_x, &e->goal_y, &e->goal2_x, &e->goal2_y};
@@ -764,18 +798,21 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     if (r == hipSuccess) r = dalloc(e, reinterpret_cast<unsigned char**>(&e->nb_idx),
                                     an * (size_t)(e->K > 0 ? e->K : 1) * (e->nidx16 ? 2 : 1));
     if (r == hipSuccess) r = dalloc(e, &e->obst_idx, an * (size_t)e->S);
-    if (r == hipSuccess) r = dalloc(e, &e->step_count, A);
-    if (r == hipSuccess) r = dalloc(e, &e->arena_done, A);
+    if (r == hipSuccess) r = dalloc(e, &e->slab, an * CA_OBS_DIM + an + 2 * A);   // observation | reward | arena_done | step_count
+    if (r == hipSuccess) {
+        e->obs = e->slab; e->reward = e->slab + an * CA_OBS_DIM;
+        e->arena_done = reinterpret_cast<int*>(e->reward + an); e->step_count = e->arena_done + A;
+    }
     if (r == hipSuccess) r = dalloc(e, &e->episode, A);
     if (r == hipSuccess) r = dalloc(e, &e->arena_stats, A * ST_STRIDE);
     if (r == hipSuccess) r = dalloc(e, &e->arena_steps, A);
-    if (r == hipSuccess) r = dalloc(e, &e->obs, an * CA_OBS_DIM);
     if (r == hipSuccess) r = dalloc(e, &e->d_obst, (size_t)1);
 #ifdef CA_STAMPS
     if (r == hipSuccess) r = dalloc(e, &e->dbg, (size_t)std::max(std::max(e->grid * (2 * e->BS / 64), e->grid_n * (e->BSn / 64)), e->grid_q * (e->BSq / 64)) * 16);
     if (r == hipSuccess) r = dalloc(e, &e->dbg_obs, (size_t)cfg->n_arenas * ((cfg->n_agents + 15) / 16 + 16) * 4 * 16);
 #endif
-    if (r == hipSuccess) r = apply_variant_attributes(e);
+    bool lds_misfit = false;
+    if (r == hipSuccess) { r = apply_variant_attributes(e); lds_misfit = r == hipErrorInvalidValue; }
     if (r == hipSuccess && e->quad_roll && e->lds_q > 48 * 1024)
         r = hipFuncSetAttribute(quad_fn(e), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_q);
     if (r == hipSuccess) {
@@ -793,6 +830,12 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         r = upload(e, e->d_cold, &hc, sizeof hc);
     }
     if (r == hipSuccess) r = hipStreamSynchronize(e->stream);  // the zero fills are done before the handle is handed out
+    if (lds_misfit) {
+        fail(nullptr, CA_ERANGE, "ca_create: the solve kernel for n_agents=%d, max_neighbors=%d, max_obst_neighbors=%d does not fit the "
+             "160 KiB of LDS of a CU", cfg->n_agents, e->K, e->S);
+        ca_destroy(e);
+        return CA_ERANGE;
+    }
     if (r != hipSuccess) {
         fail(nullptr, CA_EHIP, "ca_create: %s", hipGetErrorString(r));
         ca_destroy(e);
@@ -807,13 +850,13 @@ int ca_destroy(ca_env* e) {
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
     void* bufs[] = {e->pos_x, e->pos_y, e->vel_x, e->vel_y, e->pref_x, e->pref_y, e->goal_x, e->goal_y,
-                    e->goal2_x, e->goal2_y, e->reward, e->tmp_x, e->tmp_y, e->orient_x, e->orient_y,
+                    e->goal2_x, e->goal2_y, e->slab, e->tmp_x, e->tmp_y, e->orient_x, e->orient_y,
                     e->agent_done, e->arrive_step,
-                    e->regoal_count, e->counts, e->nb_idx, e->obst_idx, e->cvt_buf, e->d_tab_off, e->d_cold, e->d_order, e->step_count,
-                    e->arena_done, e->episode, e->arena_stats, e->arena_steps, e->d_obst, e->dbg, e->dbg_obs,
+                    e->regoal_count, e->counts, e->nb_idx, e->obst_idx, e->cvt_buf, e->d_tab_off, e->d_cold, e->d_order,
+                    e->episode, e->arena_stats, e->arena_steps, e->d_obst, e->dbg, e->dbg_obs,
                     e->alan_w, e->alan_t, e->alan_dirs, e->alan_u, e->alan_action, e->d_alan, e->mask_buf};
     for (void* b : bufs) if (b) hipFree(b);
-    if (e->obs && !e->obs_external) hipFree(e->obs);
+    for (const auto& h : e->host_allocs) hipHostFree(h.first);
     for (const ca_env::Span& sp : e->spans) { hipEventDestroy(sp.t0); hipEventDestroy(sp.t1); }
     for (hipEvent_t ev : e->free_events) hipEventDestroy(ev);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -843,8 +886,13 @@ static int build_table(ca_env* e, const float* verts_xy, const int32_t* poly_siz
             const V2 pt = mk(verts_xy[2 * (off + i)], verts_xy[2 * (off + i) + 1]);
             const V2 pn = mk(verts_xy[2 * (off + in)], verts_xy[2 * (off + in) + 1]);
             const V2 pp = mk(verts_xy[2 * (off + ip)], verts_xy[2 * (off + ip) + 1]);
+            if (!(fabsf(pt.x) <= CA_MAX_COORD && fabsf(pt.y) <= CA_MAX_COORD))   // (also false for NaN)
+                return fail(e, CA_ERANGE, "ca_set_obstacles: polygon %d vertex %d = (%g, %g) is beyond %g or not a number", pi, i,
+                            (double)pt.x, (double)pt.y, (double)CA_MAX_COORD);
             if (pn.x == pt.x && pn.y == pt.y)
                 return fail(e, CA_EINVAL, "ca_set_obstacles: polygon %d has an edge of length zero (vertex %d twice)", pi, i);
+            if (absSq(pn - pt) < CA_MIN_EDGE * CA_MIN_EDGE)
+                return fail(e, CA_ERANGE, "ca_set_obstacles: polygon %d edge %d is shorter than %g", pi, i, (double)CA_MIN_EDGE);
             const V2 u = normalize(pn - pt);
             ObstDev o;
             memset(&o, 0, sizeof o);
@@ -909,7 +957,13 @@ static int install_tables(ca_env* e, std::vector<ObstDev>& all, std::vector<int>
     else for (size_t a = 0; a + 1 < e->h_tab_off.size(); ++a) me = std::max(me, e->h_tab_off[a + 1] - e->h_tab_off[a]);
     e->max_edges = me;
     pick_variant(e);
-    HIPCHK(e, apply_variant_attributes(e));
+    {
+        const hipError_t ra = apply_variant_attributes(e);
+        if (ra == hipErrorInvalidValue)
+            return fail(e, CA_ERANGE, "ca_set_obstacles: the solve kernel this world selects does not fit the 160 KiB of LDS of a CU "
+                        "(n_agents=%d, max_neighbors=%d, max_obst_neighbors=%d)", e->cfg.n_agents, e->K, e->S);
+        HIPCHK(e, ra);
+    }
     return alan_pick(e);   // (the form of the ALAN step follows the solve kernel)
 }
 
@@ -1277,8 +1331,7 @@ int ca_bind_obs(ca_env* e, void* dev_ptr, size_t bytes) {
     if (((uintptr_t)dev_ptr & 15) != 0) return fail(e, CA_EINVAL, "ca_bind_obs: buffer must be 16-byte aligned");
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (e->obs && !e->obs_external) HIPCHK(e, hipFree(e->obs));
-    e->obs = (float*)dev_ptr;
+    e->obs = (float*)dev_ptr;   // (the library's own observation buffer is part of the result slab and stays allocated)
     e->obs_external = true;
     return CA_OK;
 }
@@ -1350,6 +1403,42 @@ int ca_step_host(ca_env* e, const float* actions_host, uint32_t flags) {
     HIPCHK(e, hipMemcpyAsync(e->tmp_x, actions_host, AN(e) * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));  // the caller's buffer may be reused right away
     return do_step(e, e->tmp_x, flags);
+}
+
+/* The host-array form of a step with ONE round trip: actions in (or NULL: the ORCA-only step), then observation | reward |
+ * arena_done | step_count out in one copy, one synchronisation at the end.  The shape the reference's callers use -- one
+ * environment per worker, results wanted on the host every step (run_rllib.py:77, 108; env.py:367-416) -- is latency:
+ * ca_step_host + three ca_get cost four synchronisations.  Buffers from ca_host_alloc are page-locked AND device-visible: such
+ * an action buffer is read by the kernel where it lies (no staging copy). */
+int ca_step_packed(ca_env* e, const float* actions_host, uint32_t flags, void* out_host, size_t out_bytes) {
+    if (!e || !out_host) return fail(e, CA_EINVAL, "ca_step_packed: null argument");
+    const size_t an = AN(e), A = (size_t)e->cfg.n_arenas;
+    const size_t obs_b = an * CA_OBS_DIM * 4, rest_b = an * 4 + 2 * A * 4;
+    if (out_bytes != obs_b + rest_b) return fail(e, CA_ESIZE, "ca_step_packed: need %zu bytes, got %zu", obs_b + rest_b, out_bytes);
+    if (actions_host && (flags & CA_F_NODONE)) return fail(e, CA_EINVAL, "ca_step_packed: CA_F_NODONE applies to the ORCA-only step");
+    HIPCHK(e, hipSetDevice(e->device));
+    const float* act = nullptr;
+    if (actions_host) {
+        bool mapped = false;
+        for (const auto& h : e->host_allocs)   // a ca_host_alloc buffer holding the whole action array: device-visible as it is
+            if ((const char*)actions_host >= (const char*)h.first && (const char*)actions_host + an * 4 <= (const char*)h.first + h.second) { mapped = true; break; }
+        if (mapped) act = actions_host;
+        else {
+            HIPCHK(e, hipMemcpyAsync(e->tmp_x, actions_host, an * 4, hipMemcpyHostToDevice, e->stream));
+            act = e->tmp_x;
+        }
+    }
+    const int rc = do_step(e, act, flags);
+    if (rc) return rc;
+    char* out = (char*)out_host;
+    if (!e->obs_external) {
+        HIPCHK(e, hipMemcpyAsync(out, e->slab, obs_b + rest_b, hipMemcpyDeviceToHost, e->stream));
+    } else {
+        HIPCHK(e, hipMemcpyAsync(out, e->obs, obs_b, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(out + obs_b, e->reward, rest_b, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));   // (also the point from which the caller may reuse its action buffer)
+    return CA_OK;
 }
 
 int ca_orca_step(ca_env* e, uint32_t flags) {
@@ -1653,6 +1742,30 @@ int ca_debug_stamps(ca_env* e, unsigned long long* out, int32_t max_waves, int32
     return CA_OK;
 }
 #endif  // CA_STAMPS
+
+/* Page-locked host memory for the results of the host-array calls (ca_get / ca_step_host into the same buffers every step:
+ * the reference hands out the same dict objects every call, env.py:463-466).  A pageable destination takes the 67-MB
+ * observation of 4096 x 64 agents at ~10 GB/s, a pinned one at the link's rate.  Owned by the handle. */
+int ca_host_alloc(ca_env* e, size_t bytes, void** out) {
+    if (!e || !out || bytes == 0) return fail(e, CA_EINVAL, "ca_host_alloc: bad argument");
+    *out = nullptr;
+    HIPCHK(e, hipSetDevice(e->device));
+    void* p = nullptr;
+    HIPCHK(e, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    e->host_allocs.push_back({p, bytes});
+    *out = p;
+    return CA_OK;
+}
+int ca_host_free(ca_env* e, void* p) {
+    if (!e || !p) return fail(e, CA_EINVAL, "ca_host_free: bad argument");
+    for (size_t k = 0; k < e->host_allocs.size(); ++k)
+        if (e->host_allocs[k].first == p) {
+            e->host_allocs.erase(e->host_allocs.begin() + k);
+            HIPCHK(e, hipHostFree(p));
+            return CA_OK;
+        }
+    return fail(e, CA_EINVAL, "ca_host_free: not a buffer of this handle");
+}
 
 int ca_profile(ca_env* e, int32_t period) {
     if (!e || period < 0) return fail(e, CA_EINVAL, "ca_profile: bad argument");

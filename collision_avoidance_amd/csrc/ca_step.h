@@ -83,8 +83,10 @@ __device__ __noinline__ void solve_many_obstacles(float4* tbl, int MLX, const Ob
 template <int KMAX, int BS, int ST, bool FUSE, int HELP = 1, int SMX = (ST > 0 ? ST : SMAX), bool ALAN = false>
 __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1) void step_kernel(const StepArgs p) {
     extern __shared__ float4 smem4[];
-    __shared__ unsigned s_vmax2;   // (BS > 64) the largest squared speed of the arena in this step, as float bits: see the pair count
-    if constexpr (BS > 64) { if (threadIdx.x == 0) s_vmax2 = 0u; }   // (barriers follow before its first use)
+    constexpr bool LISTP = BS > 64;   // the pair count of the statistics goes through the neighbour lists (arenas within one wave: the
+    //                                   scan of the staged arena is as fast -- round 5 measured the lists there: 57.7 against 57.3 us)
+    __shared__ unsigned s_vmax2;   // (LISTP) the largest squared speed of the workgroup's arenas in this step, as float bits: see the pair count
+    if constexpr (LISTP) { if (threadIdx.x == 0) s_vmax2 = 0u; }   // (barriers follow before its first use)
     CA_PRIO_START();
     // FUSE: the neighbour search runs at the head of this kernel instead of in a launch of its own (one
     // drain/fill less per step, and its dispatch skew overlaps useful work).  A lane later reads back only the
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
         }
     }
 
-    if constexpr (BS > 64) {   // how far does any agent of the arena move in this step?  (one arena per workgroup at these sizes)
+    if constexpr (LISTP) {   // how far does any agent of the arena move in this step?
         const unsigned sp = wave_max_u32(active ? __float_as_uint(absSq(vel)) : 0u);
         if ((tid & 63) == 63) atomicMax(&s_vmax2, sp);
     }
@@ -491,9 +493,9 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
         int pairs = 0;
         const float crSq = sqr(R + R);
         float m2 = 0.0f;   // 2 m, a hair wide for the rounding of the update (NaN / infinite speeds fail every test below: full scan)
-        if constexpr (BS > 64) m2 = 2.0002f * __builtin_sqrtf(__uint_as_float(s_vmax2)) * p.time_step;
-        bool scan_all = active && !(BS > 64 && p.neighbor_dist >= R + R + m2);  // arenas within one wave: the scan is cheaper
-        if constexpr (BS > 64) if (active && !scan_all) {
+        if constexpr (LISTP) m2 = 2.0002f * __builtin_sqrtf(__uint_as_float(s_vmax2)) * p.time_step;
+        bool scan_all = active && !(LISTP && p.neighbor_dist >= R + R + m2);
+        if constexpr (LISTP) if (active && !scan_all) {
             float far2 = 0.0f;
             const int ncnt = (int)(p.counts[q] & 0xFFu);  // read again (this lane wrote it): not kept in a register across the solve
             int jn[KMAX];  // all list entries in flight at once

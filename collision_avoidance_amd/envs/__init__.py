@@ -96,8 +96,8 @@ class Collision_Avoidance_Env(*_bases):
 
     def step(self, action):
         # env.py:367-416.  A missing agent key raises KeyError like the reference (env.py:373).
-        act = np.array([float(np.asarray(action[k]).reshape(-1)[0]) for k in self._keys], np.float32)
-        obs, rew, done, _ = self.vec.step(act.reshape(1, -1))
+        act = [float(np.asarray(action[k]).reshape(-1)[0]) for k in self._keys]
+        obs, rew, done, _ = self.vec.step_packed(act)      # one round trip: actions in, obs | reward | done out (ca_step_packed)
         for k, r in zip(self._keys, rew[0].tolist()):
             self.gym_rewards[k] = r
         self.gym_dones['__all__'] = bool(done[0])
@@ -106,7 +106,7 @@ class Collision_Avoidance_Env(*_bases):
 
     def orca_step(self, action=None):
         # env.py:447-458 (no done test, no step counter); returns None, updates self.gym_obs
-        self._fill_obs(self.vec.orca_step(with_obs=True, no_done=True))
+        self._fill_obs(self.vec.step_packed(None, no_done=True)[0])
 
     def seed(self, seed=None):
         # env.py:494-496 returns [seed]; here the seed also keys the spawn draws of later resets

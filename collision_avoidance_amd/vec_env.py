@@ -93,6 +93,7 @@ class VecCollisionAvoidanceEnv:
         _lib.check(self.L, self.h, rc, name)
 
     def close(self):
+        self.__dict__.pop("_host_bufs", None); self.__dict__.pop("_packed", None); self.__dict__.pop("_packed_act", None)
         if getattr(self, "h", None):
             self.L.ca_destroy(self.h)
             self.h = None
@@ -123,6 +124,8 @@ class VecCollisionAvoidanceEnv:
         """Host copy of a state field (synchronises the stream).  out: a C-contiguous array of the field's device shape and
         dtype to fill instead of a new one (e.g. host_buffer(field): page-locked, so the copy runs at the link's rate)."""
         shape, dt = self._shape_dtype(field)
+        if out is not None and field in (_lib.FLD_ALAN_WEIGHTS, _lib.FLD_ALAN_TIMES):
+            raise ValueError("get: out= is not supported for the ALAN weights / times (they are returned transposed, [A, N, n_actions])")
         if out is None:
             out = np.empty(shape, dt)
         elif out.shape != tuple(shape) or out.dtype != np.dtype(dt) or not out.flags["C_CONTIGUOUS"]:
@@ -132,24 +135,46 @@ class VecCollisionAvoidanceEnv:
             return np.ascontiguousarray(np.transpose(out, (0, 2, 1)))   # [A, N, n_actions] like ALAN_true.py:75-76
         return out
 
+    def host_array(self, shape, dtype):
+        """A numpy array over page-locked, device-visible host memory from the library (ca_host_alloc: no PyTorch involved);
+        owned by the handle, released by close()."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = C.c_void_p()
+        self._call("ca_host_alloc", self.h, max(n, 1), C.byref(ptr))
+        buf = (C.c_char * max(n, 1)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
     def host_buffer(self, field):
-        """A persistent host array for a field, page-locked when PyTorch can allocate pinned memory (a pageable destination
-        takes the 67-MB observation of 4096 x 64 agents at ~10 GB/s, a pinned one at the PCIe rate).  Owned by the
-        environment and reused by step(copy=False): valid until the next call that writes it -- the reference's own
-        ownership rule (env.py:463-466: the same dict objects every call, mutated in place)."""
+        """A persistent page-locked host array for a field (a pageable destination takes the 67-MB observation of 4096 x 64
+        agents at ~10 GB/s, a pinned one at the PCIe rate).  Owned by the environment and reused by step(copy=False): valid until
+        the next call that writes it -- the reference's own ownership rule (env.py:463-466: the same dict objects every call,
+        mutated in place)."""
         bufs = self.__dict__.setdefault("_host_bufs", {})
         if field not in bufs:
             shape, dt = self._shape_dtype(field)
-            arr = None
-            if torch is not None and torch.cuda.is_available():
-                try:
-                    t = torch.empty(tuple(shape), dtype=getattr(torch, np.dtype(dt).name), pin_memory=True)
-                    arr = t.numpy()
-                    self.__dict__.setdefault("_host_pins", []).append(t)    # keeps the pinned storage alive
-                except Exception:
-                    arr = None
-            bufs[field] = np.empty(shape, dt) if arr is None else arr
+            bufs[field] = self.host_array(shape, dt)
         return bufs[field]
+
+    def step_packed(self, actions=None, with_obs=True, stats=False, autoreset=False, no_done=False):
+        """One host-side step in one round trip (ca_step_packed): actions [A,N] (None: the ORCA-only step) in, (obs, rewards, dones,
+        step_counts) out as views of ONE page-locked buffer owned by the environment, valid until the next call.  The form for one
+        environment per worker with results on the host every step (run_rllib.py:77, 108)."""
+        an, A = self.A * self.N, self.A
+        if "_packed" not in self.__dict__:
+            words = an * _lib.OBS_DIM + an + 2 * A
+            raw = self.host_array((words,), np.float32)
+            self._packed = (raw, raw[:an * _lib.OBS_DIM].reshape(A, self.N, _lib.OBS_DIM), raw[an * _lib.OBS_DIM:an * _lib.OBS_DIM + an].reshape(A, self.N),
+                            raw[an * _lib.OBS_DIM + an:an * _lib.OBS_DIM + an + A].view(np.int32), raw[an * _lib.OBS_DIM + an + A:].view(np.int32))
+            self._packed_act = self.host_array((A, self.N), np.float32)
+        raw, obs, rew, done, steps = self._packed
+        flags = (_lib.F_OBS if with_obs else 0) | (_lib.F_STATS if stats else 0) | (_lib.F_AUTORESET if autoreset else 0) | \
+                (_lib.F_NODONE if no_done else 0)
+        act_ptr = None
+        if actions is not None:
+            self._packed_act[...] = np.asarray(actions, np.float32).reshape(A, self.N)
+            act_ptr = self._packed_act.ctypes.data
+        self._call("ca_step_packed", self.h, act_ptr, flags, raw.ctypes.data, raw.nbytes)
+        return obs, rew, done, steps
 
     def set(self, field, arr):
         shape, dt = self._shape_dtype(field)
@@ -161,18 +186,20 @@ class VecCollisionAvoidanceEnv:
     # ---- checkpoint / resume -------------------------------------------------------------------------
     _STATE_FIELDS = ("POS_X", "POS_Y", "VEL_X", "VEL_Y", "PREF_X", "PREF_Y", "GOAL_X", "GOAL_Y", "GOAL2_X", "GOAL2_Y",
                      "AGENT_DONE", "ARRIVE_STEP", "NB_COUNT", "NB_IDX", "OBST_COUNT", "OBST_IDX", "STEP_COUNT", "ARENA_DONE",
-                     "EPISODE", "REGOAL_COUNT")
+                     "EPISODE", "REGOAL_COUNT", "REWARD")
 
     def get_state(self):
         """Everything the next step depends on, as a dict of host arrays: simulator state, targets, the neighbour lists of
         the last doStep (the observation of a reset reads them, env.py:461-488), the counters that key the random draws
-        (episode, re-goal count, step count) and, after alan_configure, the bandit's weights and times.  The reference never
+        (episode, re-goal count, step count), the last rewards (an arena frozen by CA_F_FREEZE keeps them) and, after alan_configure,
+        the bandit's weights, times and last actions.  The reference never
         serialises its environment (checkpoints exist at the trainer's level only); with counter-based
         draws a restored environment continues bit for bit.  Statistics counters are not part of the state."""
         st = {name: self.get(getattr(_lib, "FLD_" + name)) for name in self._STATE_FIELDS}
         if self.n_actions > 0:
             st["ALAN_WEIGHTS"] = self.get(_lib.FLD_ALAN_WEIGHTS)
             st["ALAN_TIMES"] = self.get(_lib.FLD_ALAN_TIMES)
+            st["ALAN_ACTION"] = self.get(_lib.FLD_ALAN_ACTION)
         st["_shape"] = np.array([self.A, self.N, self.K, self.S, self.n_actions], np.int64)
         return st
 
@@ -184,10 +211,13 @@ class VecCollisionAvoidanceEnv:
             raise ValueError("set_state: the state is of an environment of shape %s, this one is %s"
                              % (shape, [self.A, self.N, self.K, self.S, self.n_actions]))
         for name in self._STATE_FIELDS:
-            self.set(getattr(_lib, "FLD_" + name), st[name])
+            if name in st:      # (REWARD joined in round 5: older snapshots restore without it)
+                self.set(getattr(_lib, "FLD_" + name), st[name])
         if self.n_actions > 0:
             self.set(_lib.FLD_ALAN_WEIGHTS, st["ALAN_WEIGHTS"])
             self.set(_lib.FLD_ALAN_TIMES, st["ALAN_TIMES"])
+            if "ALAN_ACTION" in st:
+                self.set(_lib.FLD_ALAN_ACTION, st["ALAN_ACTION"])
 
     def field_tensor(self, field):
         """Zero-copy torch view of a state field's device buffer (valid until close(); kernels of this handle run on

@@ -100,6 +100,20 @@ enum ca_field {
     CA_FLD__COUNT
 };
 
+/* Units and magnitudes.  The kernels compute in fp32 with a correctly rounded division and square root that omit the
+ * range-scaling steps of the general sequences (exact where quotients, discriminants and lengths stay well inside the normal
+ * range: csrc/ca_math.h).  That holds for worlds in units of O(1) -- the reference's are metres and seconds: radius 0.5,
+ * max_speed 1, time_step 1/60, arenas of 10-50 (env.py:26-44, ALAN_true.py:14-20) -- and is ENFORCED at the boundary:
+ * ca_create refuses (CA_ERANGE) a configuration outside the ranges below, ca_set_obstacles a vertex beyond CA_MAX_COORD
+ * or an edge shorter than CA_MIN_EDGE.  Positions and targets handed in through ca_set / ca_reset are device data and are
+ * not checked: keep them within CA_MAX_COORD of the origin. */
+#define CA_MIN_LENGTH 1e-3f      /* radius, max_speed, neighbor_dist, time_horizon, time_horizon_obst: [1e-3, 1e3] */
+#define CA_MAX_LENGTH 1e3f
+#define CA_MIN_TIME_STEP 1e-4f   /* time_step: [1e-4, 10] */
+#define CA_MAX_TIME_STEP 10.0f
+#define CA_MAX_COORD 1e5f        /* obstacle vertices, spawn / goal boxes: |x|, |y| <= 1e5 */
+#define CA_MIN_EDGE 1e-4f        /* an obstacle edge is at least this long */
+
 /* Replaces the constants the reference hard-codes in Collision_Avoidance_Env.__init__
  * (env.py:27-44), the literal at env.py:130, and the per-call arguments of
  * rvo2.PyRVOSimulator / addAgent (env.py:62-68, 126-133; ALAN:22-28). */
@@ -177,6 +191,10 @@ int ca_init_scenario(ca_env* env, int32_t scenario);
  * env.py:157, 237, 479): whole-array copies.  *_is_device: the caller's pointer is device memory. */
 int ca_set(ca_env* env, int32_t field, const void* src, size_t bytes, int32_t src_is_device);
 int ca_get(ca_env* env, int32_t field, void* dst, size_t bytes, int32_t dst_is_device);
+/* Page-locked, device-visible host memory owned by the handle (freed by ca_host_free or ca_destroy): the destination of the
+ * host-array calls at the link's rate instead of a pageable copy's, and an action buffer the kernels read where it lies. */
+int ca_host_alloc(ca_env* env, size_t bytes, void** out);
+int ca_host_free(ca_env* env, void* p);
 /* Zero-copy view of a field's device buffer (valid until ca_destroy / ca_bind_obs). */
 int ca_field_ptr(ca_env* env, int32_t field, void** dev_ptr, size_t* bytes);
 /* Let the caller own the observation buffer (e.g. a torch tensor [A,N,64] f32 on this device). */
@@ -194,6 +212,13 @@ int ca_reset_masked(ca_env* env, const int32_t* mask, int32_t mask_is_device, ui
 int ca_step(ca_env* env, const float* actions, uint32_t flags);
 /* Same, with the actions in HOST memory (copied to the device on the handle's stream). */
 int ca_step_host(ca_env* env, const float* actions_host, uint32_t flags);
+/* A whole host-side step in ONE round trip -- what one environment per worker needs (run_rllib.py:77, 108; env.py:367-416: the
+ * four dictionaries every step): actions in (NULL: the ORCA-only step, env.py:447-458), then
+ *   out_host = [ observation A*N*64 f32 | reward A*N f32 | arena_done A i32 | step_count A i32 ]
+ * in one device-to-host copy and one synchronisation (ca_step_host + three ca_get make four).  out_bytes must be the size of
+ * that layout.  Buffers from ca_host_alloc make the copy run at the link's rate; an action buffer from ca_host_alloc is read by
+ * the kernel where it lies.  Without CA_F_OBS the observation part holds the last one computed. */
+int ca_step_packed(ca_env* env, const float* actions_host, uint32_t flags, void* out_host, size_t out_bytes);
 /* Replaces orca_step (env.py:447-458; ALAN:631-636 + the done test of ALAN:118-121). */
 int ca_orca_step(ca_env* env, uint32_t flags);
 /* Replaces _get_obs() alone (env.py:231-277): recompute the observation of the current state. */

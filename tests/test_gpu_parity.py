@@ -743,6 +743,7 @@ def test_checkpoint_and_resume_continue_bit_for_bit(with_alan, tmp_path):
                 env.step(acts[s], stats=True, autoreset=True)
     advance(a, 0, 25)
     st = a.get_state()
+    assert "REWARD" in st and (not with_alan or "ALAN_ACTION" in st)
     np.savez(tmp_path / "ckpt.npz", **st)
     advance(a, 25, 45)
     b = H.make_gpu(A, N, "crowd", p, seed=9)    # a fresh handle: its own scenario draws are overwritten by the snapshot
@@ -750,6 +751,14 @@ def test_checkpoint_and_resume_continue_bit_for_bit(with_alan, tmp_path):
         b.alan_configure(alan.DEFAULT_ACTIONS)
     with np.load(tmp_path / "ckpt.npz") as z:
         b.set_state({k: z[k] for k in z.files})
+    for f in [_lib.FLD_REWARD] + ([_lib.FLD_ALAN_ACTION] if with_alan else []):      # readable right after the restore
+        assert np.array_equal(b.get(f), st["REWARD" if f == _lib.FLD_REWARD else "ALAN_ACTION"])
+    a2 = H.make_gpu(A, N, "crowd", p, seed=9)     # ... and an observation taken right after the restore is the snapshot's own
+    if with_alan:
+        a2.alan_configure(alan.DEFAULT_ACTIONS)
+    a2.set_state(st)
+    assert np.array_equal(a2.observe(), b.observe())
+    a2.close()
     advance(b, 25, 45)
     fields = [getattr(_lib, "FLD_" + n) for n in a._STATE_FIELDS] + [_lib.FLD_OBS, _lib.FLD_REWARD]
     if with_alan:
@@ -765,3 +774,70 @@ def test_checkpoint_and_resume_continue_bit_for_bit(with_alan, tmp_path):
     with pytest.raises(ValueError):
         H.make_gpu(A + 1, N, "crowd", p, seed=9).set_state(st)
     a.close(); b.close()
+
+
+def test_step_packed_is_the_step_in_one_round_trip():
+    """ca_step_packed: actions in, observation | reward | arena_done | step_count out in one copy -- the same bits as
+    ca_step_host + three ca_get, for the full step, the ORCA-only step and with an externally bound observation buffer;
+    the drop-in class (one environment, the reference's usage: run_rllib.py:77, 108) goes through it."""
+    from collision_avoidance_amd import _lib
+    A, N = 3, 10
+    p = scenarios.env_params()
+    a = H.make_gpu(A, N, "doorway", p, seed=4)
+    b = H.make_gpu(A, N, "doorway", p, seed=4)
+    rng = np.random.RandomState(2)
+    for s in range(40):
+        act = rng.uniform(-0.6, 0.6, (A, N)).astype(np.float32)
+        if s % 7 == 6:
+            ob_a = a.orca_step(with_obs=True, no_done=True)
+            ob_b, rew_b, done_b, cnt_b = b.step_packed(None, no_done=True)
+            rew_a, done_a = a.get(_lib.FLD_REWARD), a.get(_lib.FLD_ARENA_DONE)
+        else:
+            ob_a, rew_a, done_a, _ = a.step(act, stats=True, autoreset=(s % 5 == 0))
+            ob_b, rew_b, done_b, cnt_b = b.step_packed(act, stats=True, autoreset=(s % 5 == 0))
+        for x, y, what in ((ob_a, ob_b, "obs"), (rew_a, rew_b, "reward"), (done_a, done_b, "done"), (a.get(_lib.FLD_STEP_COUNT), cnt_b, "steps")):
+            assert np.array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8)), (s, what)
+    orc = H.make_oracle(A, N, "doorway", p, seed=4)
+    rng = np.random.RandomState(2)
+    for s in range(40):
+        act = rng.uniform(-0.6, 0.6, (A, N)).astype(np.float32)
+        if s % 7 == 6:
+            orc.orca_step(flags=o.F_OBS | o.F_NODONE)
+        else:
+            orc.step(act, flags=o.F_OBS | o.F_STATS | (o.F_AUTORESET if s % 5 == 0 else 0))
+    H.assert_state_equal(b, orc, "packed steps", obs=True)
+    with pytest.raises(RuntimeError, match="need"):
+        b._call("ca_step_packed", b.h, None, 0, b._packed[0].ctypes.data, 8)
+    with pytest.raises(ValueError):
+        b.get(_lib.FLD_ALAN_WEIGHTS, out=np.zeros((A, 1, N)))
+    a.close(); b.close()
+    t = H.make_gpu(2, 6, "crowd", H.scenario_params("crowd", 6), seed=1, use_torch=True)     # observation bound to a torch tensor
+    u = H.make_gpu(2, 6, "crowd", H.scenario_params("crowd", 6), seed=1)
+    act = np.linspace(-0.5, 0.5, 12).astype(np.float32).reshape(2, 6)
+    ob_t, rew_t, done_t, cnt_t = t.step_packed(act)
+    ob_u, rew_u, done_u, _ = u.step(act)
+    assert np.array_equal(ob_t, ob_u) and np.array_equal(rew_t, rew_u) and np.array_equal(done_t, done_u)
+    t.close(); u.close()
+
+
+def test_magnitudes_and_lds_are_checked_at_the_boundary():
+    """obstacle tables outside the supported magnitudes are refused (the previous table stays), and a handle reads
+    its diagnostic environment switches once, at ca_create."""
+    import os
+    from collision_avoidance_amd import _lib
+    env = H.make_gpu(2, 8, "crowd", H.scenario_params("crowd", 8), seed=1)
+    before = env.obstacle_table()["verts"].copy()
+    for poly, what in (([(0, 0), (2e5, 0), (1, 1)], "beyond"), ([(0, 0), (1e-6, 0), (1, 1)], "shorter"),
+                       ([(0, 0), (float("nan"), 0), (1, 1)], "beyond")):
+        with pytest.raises(RuntimeError, match=what):
+            env.set_obstacles([poly])
+    np.testing.assert_array_equal(env.obstacle_table()["verts"], before)
+    lanes = env.launch_info()["lanes_per_agent"]
+    os.environ["CA_QUAD"] = "0"; os.environ["CA_REG_LINES"] = "0"
+    try:
+        env.set_obstacles(scenarios.obstacles("crowd", 8))           # re-selects the kernel: from the LATCHED switches
+        assert env.launch_info()["lanes_per_agent"] == lanes
+        env.step(np.zeros((2, 8), np.float32))
+    finally:
+        del os.environ["CA_QUAD"]; del os.environ["CA_REG_LINES"]
+    env.close()

@@ -74,6 +74,15 @@ def test_argument_validation_without_gpu():
     bad = _lib.Config(n_arenas=1, n_agents=4, max_obst_neighbors=1, **dict(scenarios.env_params(), max_neighbors=17))
     assert L.ca_create(C.byref(bad), 0, None, C.byref(h)) == -5
     assert L.ca_create(None, 0, None, C.byref(h)) == -1
+    # units and magnitudes (include/ca_env.h): the in-range division / square root of the kernels are exact for worlds of O(1)
+    # units only, so a configuration outside the documented ranges is refused at the boundary, not silently inexact
+    for field, val in (("radius", 5e-7), ("radius", 2e3), ("time_step", 1e-6), ("time_step", 60.0), ("max_speed", 0.0),
+                       ("neighbor_dist", float("nan")), ("time_horizon", 1e4), ("spawn_x1", 3e5), ("goal_y0", float("inf"))):
+        bad = _lib.Config(n_arenas=1, n_agents=4, max_obst_neighbors=1, **dict(scenarios.env_params(), **{field: val}))
+        assert L.ca_create(C.byref(bad), 0, None, C.byref(h)) == -5 and not h.value, (field, val)
+        assert field.encode() in L.ca_last_error(None) or b"box coordinate" in L.ca_last_error(None), L.ca_last_error(None)
+    for macro in ("CA_MIN_LENGTH", "CA_MAX_LENGTH", "CA_MIN_TIME_STEP", "CA_MAX_TIME_STEP", "CA_MAX_COORD", "CA_MIN_EDGE"):
+        assert re.search(r"#define %s " % macro, _header()), macro
 
 
 def test_product_never_touches_the_oracle():
