@@ -139,6 +139,11 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     }
     const int abase = DENSE ? (a - a_lo) * N : 0;   // LDS index of agent 0 of this group's arena
     const size_t q = (size_t)a * N + (active ? i : 0);
+    // One arena per workgroup (not DENSE): the arena's part of every address is the same for all lanes -- a scalar base -- and a
+    // lane adds a 32-bit offset inside the arena, so the loads and the row store below take the "scalar base + vector offset" form
+    // and no lane does 64-bit address arithmetic (it was 35 of the wave's ~575 vector instructions).
+    const size_t aoff = (size_t)a * N;
+    const unsigned ii = active ? (unsigned)i : 0u;
     const ObstDev* tab = p.obst + (p.tab_off ? p.tab_off[a] : 0);  // this arena's edge table
 
     const int NST = p.nstage_max;   // agents staged at most (N; dense: up to 16 + 2 N)
@@ -169,19 +174,35 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
     const float* gvx = p.vel_x + (size_t)a * N;
     const float* gvy = p.vel_y + (size_t)a * N;
     if constexpr (!GATHER) {
-        for (int t = tid; t < nstage; t += OBS_BS) {   // (the staged arenas are contiguous in memory)
-            const size_t qa = (size_t)a_lo * N + t;
-            s_px[t] = p.pos_x[qa]; s_py[t] = p.pos_y[qa]; s_vx[t] = p.vel_x[qa]; s_vy[t] = p.vel_y[qa];
+        if constexpr (DENSE) {
+            for (int t = tid; t < nstage; t += OBS_BS) {   // (the staged arenas are contiguous in memory)
+                const size_t qa = (size_t)a_lo * N + t;
+                s_px[t] = p.pos_x[qa]; s_py[t] = p.pos_y[qa]; s_vx[t] = p.vel_x[qa]; s_vy[t] = p.vel_y[qa];
+            }
+        } else {
+            for (unsigned t = tid; t < (unsigned)nstage; t += OBS_BS) {
+                s_px[t] = (p.pos_x + aoff)[t]; s_py[t] = (p.pos_y + aoff)[t]; s_vx[t] = (p.vel_x + aoff)[t]; s_vy[t] = (p.vel_y + aoff)[t];
+            }
         }
     }
     int nn = 0, ns = 0;
     float c = 1.0f, s = 0.0f;
     if (active) {
-        const int cnts = p.counts[q];
-        nn = cnts & 0xFF; ns = cnts >> 8;
-        c = p.orient_x[q]; s = -p.orient_y[q];  // utils.py:48-51: cos/sin of -atan2(orientation)
-        if (r < nn) s_nb[g * 16 + r] = (GATHER ? 0 : abase) + ld_idx_t<NW16>(p.nb_idx, ((size_t)a * K + r) * N + i);  // as an index of the staged arrays
-        if (r < ns) s_ob[g * 16 + r] = (int)p.obst_idx[((size_t)a * S + r) * N + i];
+        if constexpr (DENSE) {
+            const int cnts = p.counts[q];
+            nn = cnts & 0xFF; ns = cnts >> 8;
+            c = p.orient_x[q]; s = -p.orient_y[q];  // utils.py:48-51: cos/sin of -atan2(orientation)
+            if (r < nn) s_nb[g * 16 + r] = abase + ld_idx_t<NW16>(p.nb_idx, ((size_t)a * K + r) * N + i);  // as an index of the staged arrays
+            if (r < ns) s_ob[g * 16 + r] = (int)p.obst_idx[((size_t)a * S + r) * N + i];
+        } else {
+            const int cnts = (p.counts + aoff)[ii];
+            nn = cnts & 0xFF; ns = cnts >> 8;
+            c = (p.orient_x + aoff)[ii]; s = -(p.orient_y + aoff)[ii];  // utils.py:48-51: cos/sin of -atan2(orientation)
+            const unsigned li = (unsigned)r * (unsigned)N + ii;     // inside the arena's [K][N] / [S][N] block: below 16 x 1024
+            const char* nbase = (const char*)p.nb_idx + aoff * (size_t)K * (NW16 ? 2 : 1);
+            if (r < nn) s_nb[g * 16 + r] = ld_idx_t<NW16>(nbase, li);  // as an index of the staged arrays (GATHER: of the arena)
+            if (r < ns) s_ob[g * 16 + r] = (int)(p.obst_idx + aoff * (size_t)S)[li];
+        }
     }
     s_key[g * 16 + r] = ~0ull;
     if (r == 0) { s_cnt[g] = 0; s_cnt2[g] = 0; }
@@ -224,8 +245,18 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         int base = 0;
         if ((tid & 63) == 63) base = atomicAdd(&s_cnt[0], incl);
         base = __builtin_amdgcn_readlane(base, 63) + (incl - w);
-        for (int t2 = 0; t2 < w; ++t2)  // (list order is irrelevant: the merge is a commutative minimum)
-            s_pair[base + t2] = (unsigned short)((g << 8) | (k << 4) | ((i0 + t2) & 15));
+        // (list order is irrelevant: the merge is a commutative minimum.)  A window is two to four rays wide unless the neighbour
+        // overlaps the agent: four predicated stores, and a rolled loop for the rare rest -- written as one `for`, the compiler
+        // builds a 16-wide vectorised loop, a 4-wide one and a remainder loop around these few stores (60 vector instructions
+        // of control per wave for ~3 stores per lane)
+        const unsigned short hd = (unsigned short)((g << 8) | (k << 4));
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2)
+            if (t2 < w) s_pair[base + t2] = (unsigned short)(hd | ((i0 + t2) & 15));
+        if (__builtin_expect(__ballot(w > 4) != 0ull, 0)) {
+#pragma clang loop vectorize(disable) unroll(disable)
+            for (int t2 = 4; t2 < w; ++t2) s_pair[base + t2] = (unsigned short)(hd | ((i0 + t2) & 15));
+        }
     }
     // (2) lane per RAY, one obstacle edge at a time: the exact test can accept a ray only if the ray's line
     // separates the edge's end points and the crossing is not behind the origin, i.e. (up to rounding, covered
@@ -438,7 +469,8 @@ __global__ __launch_bounds__(OBS_BS) void obs_kernel(const ObsArgs p) {
         // state out of the L2 that the next solve reads it from
         typedef float v4f __attribute__((ext_vector_type(4)));
         const v4f out = {bx, by, vx, vy};
-        __builtin_nontemporal_store(out, reinterpret_cast<v4f*>(p.obs) + (q * 16 + r));
+        if constexpr (DENSE) __builtin_nontemporal_store(out, reinterpret_cast<v4f*>(p.obs) + (q * 16 + r));
+        else __builtin_nontemporal_store(out, (reinterpret_cast<v4f*>(p.obs) + aoff * 16) + (ii * 16u + (unsigned)r));
     }
     CA_OSTAMP(8);
 }
