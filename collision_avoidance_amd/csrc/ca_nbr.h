@@ -287,22 +287,31 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
         const unsigned lowmask = (unsigned)(P - 1);
         const unsigned top = __float_as_uint(rangeSq0);                  // a passing candidate's bits lie below it
         const unsigned span = 0xFFFFFFFFu >> p.logP;                     // images 0 .. span - 2 (the composite never is ~0)
-        const unsigned u0 = top >= span ? top - span + 1u : 0u;          // bit patterns up to u0 share image 0
+        const unsigned u0 = top - span + 1u;   // bit patterns up to u0 share image 0 (top >= span: neighbor_dist >= CA_MIN_LENGTH, ca_create)
         unsigned ck[KMAX + 1];
 #pragma unroll
         for (int k = 0; k <= KMAX; ++k) ck[k] = (k < kofs) ? 0u : 0xFFFFFFFFu;
-        V2 o_next = mk(s_px[lbase], s_py[lbase]);
-        for (int j = 0; j < N; ++j) {
-            const V2 o = o_next;
-            if (j + 1 < N) o_next = mk(s_px[lbase + j + 1], s_py[lbase + j + 1]);
+        auto visit = [&](int j, V2 o) __attribute__((always_inline)) {
             const float dsq = absSq(pos - o);
             const bool pass = active && j != i && dsq < rangeSq0;
             const unsigned u = __float_as_uint(dsq);
-            const unsigned c = pass ? ((((u > u0 ? u : u0) - u0) << p.logP) | (unsigned)j) : 0xFFFFFFFFu;
+            unsigned key = (((u > u0 ? u : u0) - u0) << p.logP) | (unsigned)j;
+            asm volatile("" : "+v"(key));   // (computed for every lane: left to itself the compiler branches around these three
+            const unsigned c = pass ? key : 0xFFFFFFFFu;   // instructions, twice per candidate; now one v_cndmask)
 #pragma unroll
             for (int k = KMAX; k >= 1; --k) ck[k] = umed3(ck[k - 1], ck[k], c);
             ck[0] = ck[0] < c ? ck[0] : c;
+        };
+        // four candidates per trip, their positions read at the head of the trip (immediate LDS offsets, no register rotation
+        // between trips: the rolled loop with a one-ahead prefetch spent 5 of its 28 vector instructions per candidate on moves
+        // and address increments)
+        int j = 0;
+        for (; j + 4 <= N; j += 4) {
+            const V2 o0 = mk(s_px[lbase + j], s_py[lbase + j]), o1 = mk(s_px[lbase + j + 1], s_py[lbase + j + 1]);
+            const V2 o2 = mk(s_px[lbase + j + 2], s_py[lbase + j + 2]), o3 = mk(s_px[lbase + j + 3], s_py[lbase + j + 3]);
+            visit(j, o0); visit(j + 1, o1); visit(j + 2, o2); visit(j + 3, o3);
         }
+        for (; j < N; ++j) visit(j, mk(s_px[lbase + j], s_py[lbase + j]));
         int cnt = 0;
         bool clamped_pair = false;   // (the list is ascending: two clamped candidates, if there are any, are its first two entries)
 #pragma unroll
