@@ -91,7 +91,9 @@ __device__ __forceinline__ int lp2(const LS& ls, int n, float radius, V2 opt, bo
 // LDS table for them halves the occupancy of this LDS-bound kernel and was measured slower
 // (profiles/r01_k_lp3_lds_negative_result.txt).
 template <int MAXL>
-__device__ __noinline__ void lp3(LdsLines ls, int n, int numObst, int begin, float radius, V2& result) {
+__device__ __noinline__ void lp3(__attribute__((address_space(3))) char* lines3, int stride, int n, int numObst, int begin, float radius,
+                                V2& result) {
+    LdsLines ls; ls.base = (float4*)lines3; ls.stride = stride;   // (the table is LDS and crosses the call boundary as such: no FLAT accesses)
     Line proj[MAXL];
     float distance = 0.0f;
     for (int i = begin; i < n; ++i) {
@@ -231,16 +233,36 @@ template <int CTRL>
 __device__ __forceinline__ float quad_xor(float v) { return __int_as_float(quad_xor<CTRL>(__float_as_int(v))); }
 
 // (stride: slots per row of the pool -- POOL_SLOTS; 1 for the single-agent table of ca_step.h solve_many_obstacles)
-// (Round 5 built the variant in which every group first walks to ITS next violated line, so that the wave runs the long body
-// max-over-groups times instead of once per position of the union: bit-exact and 4-8 % SLOWER on C2, C3 and C5 -- the walks are
-// chains of dependent LDS reads whose lengths add up over the body executions; profiles/r05_b_simd_balance_and_lp3_walk.txt.)
-__device__ __noinline__ void lp3_coop(float4* pool, int ML, int nslots, float radius, int stride = POOL_SLOTS) {
+// (Round 5 built two variants in which a group goes straight to ITS next violated line, so that the wave runs the long body
+// max-over-groups times instead of once per position of the union -- each group walking there one read at a time: 4-8 % slower
+// everywhere; the group's four lanes testing the remaining lines together (two reads in flight, a quad minimum): C3 -0.7 %, C5
+// +1.2 %, C2 +9 % -- neither kept: profiles/r05_b_simd_balance_and_lp3_walk.txt.)
+// The pool is LDS, and lp3_coop is told so: through a generic `float4*` across the call boundary every access was a FLAT
+// instruction (aperture check, both memory counters) in the middle of these latency chains; with an address-space-3 pointer they
+// are ds_read_b128 / ds_write_b128.
+typedef float lp3_v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) lp3_v4f lp3_lds_v4f;
+struct Lds3Lines {  // [line][slot] float4 = (point.x, point.y, dir.x, dir.y), in LDS
+    lp3_lds_v4f* base;  // already offset by the slot
+    int stride;
+    __device__ __forceinline__ Line get(int j) const {
+        const lp3_v4f v = base[j * stride];
+        Line l; l.point = mk(v.x, v.y); l.dir = mk(v.z, v.w);
+        return l;
+    }
+    __device__ __forceinline__ void put(int j, const Line& l) const {
+        const lp3_v4f v = {l.point.x, l.point.y, l.dir.x, l.dir.y};
+        base[j * stride] = v;
+    }
+};
+__device__ __noinline__ void lp3_coop_lds(lp3_lds_v4f* pool, int ML, int nslots, float radius, int stride) {
     const int lane = threadIdx.x & 63, slot = lane >> 2, q = lane & 3;
-    float4* hdr = pool + (size_t)(2 * ML - 1) * stride;
-    LdsLines ls; ls.base = pool + slot; ls.stride = stride;
-    LdsLines pj; pj.base = pool + (size_t)ML * stride + slot; pj.stride = stride;
+    lp3_lds_v4f* hdr = pool + (2 * ML - 1) * stride;
+    Lds3Lines ls; ls.base = pool + slot; ls.stride = stride;
+    Lds3Lines pj; pj.base = pool + ML * stride + slot; pj.stride = stride;
     const bool live = slot < nslots;
-    const float4 h = live ? hdr[slot] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    lp3_v4f h = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (live) h = hdr[slot];
     const int packed = __float_as_int(h.z);
     const int n = live ? (packed & 0xFF) : 0, numObst = (packed >> 8) & 0xFF, begin = (packed >> 16) & 0xFF;
     const int gshift = lane & ~3;
@@ -317,7 +339,10 @@ __device__ __noinline__ void lp3_coop(float4* pool, int ML, int nslots, float ra
             wave_lds_sync();  // the projected lines are rewritten for the next violated line
         }
     }
-    if (live && q == 0) hdr[slot] = make_float4(result.x, result.y, h.z, 0.0f);
+    if (live && q == 0) { const lp3_v4f o = {result.x, result.y, h.z, 0.0f}; hdr[slot] = o; }
+}
+__device__ __forceinline__ void lp3_coop(float4* pool, int ML, int nslots, float radius, int stride = POOL_SLOTS) {
+    lp3_coop_lds((lp3_lds_v4f*)pool, ML, nslots, radius, stride);
 }
 
 }  // namespace ca

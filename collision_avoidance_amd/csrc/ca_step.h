@@ -36,11 +36,19 @@ typedef const __attribute__((address_space(4))) StepCold ColdK;  // the cold blo
 // RVO2 keeps every edge in range (env.py:249, 301-318), so the list capacity stays 16; in the reference's doorway and
 // "congested" worlds (14 edges) no agent-step of 3.8e5 sampled had more than four (profiles/r04_b_reference_worlds.txt),
 // which is what lets those worlds run on the register-line kernel.  Not inlined: the hot path's registers are not its.
+// (the pointers cross the call boundary WITH their address spaces -- LDS for the table and the staged arena, global for the edge
+// records and the lists: as generic pointers every access in here was a FLAT instruction)
+#define CA_AS(n) __attribute__((address_space(n)))
 template <bool NW16, int TS>
-__device__ __noinline__ void solve_many_obstacles(float4* tbl, int MLX, const ObstDev* tab, const unsigned short* oidx, const void* nidx,
-                                                 int stride, int ocnt, int ncnt, const float* arena, int bs, V2 pos, V2 vel, V2 pref,
-                                                 float R, float invTO, float invT, float invDt, float max_speed) {
+__device__ __noinline__ void solve_many_obstacles(CA_AS(3) char* tbl3, int MLX, const CA_AS(1) char* tab1, const CA_AS(1) char* oidx1,
+                                                 const CA_AS(1) char* nidx1, int stride, int ocnt, int ncnt, const CA_AS(3) char* arena3, int bs,
+                                                 V2 pos, V2 vel, V2 pref, float R, float invTO, float invT, float invDt, float max_speed) {
     // (few enough arguments to travel in registers: one on the stack would give the whole kernel a scratch segment)
+    float4* tbl = (float4*)tbl3;
+    const ObstDev* tab = (const ObstDev*)tab1;
+    const unsigned short* oidx = (const unsigned short*)oidx1;
+    const void* nidx = (const void*)nidx1;
+    const float* arena = (const float*)arena3;
     const float *ax = arena, *ay = arena + bs, *avx = arena + 2 * bs, *avy = arena + 3 * bs;  // the staged arena: px | py | vx | vy
     LdsLines ls; ls.base = tbl; ls.stride = TS;
     int nl = 0;
@@ -335,9 +343,10 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
                     const bool mine = need_o && rank < GX;
                     if (mine) {
                         const ObstDev* tab_o = p.obst + (p.tab_off != nullptr ? p.tab_off[a_o] : 0);
-                        solve_many_obstacles<CA_NBW16(BS), GX>(pool + rank, MLX, tab_o, obst_idx_s + (size_t)a_o * S * N + i_o,
-                                                               (const char*)nb_idx_s + ((size_t)a_o * K * N + i_o) * (CA_NBW16(BS) ? 2 : 1), N,
-                                                               cnts_o >> 8, cnts_o & 0xFF, s_px + (tid_o - i_o), BS,
+                        solve_many_obstacles<CA_NBW16(BS), GX>((CA_AS(3) char*)(pool + rank), MLX, (const CA_AS(1) char*)tab_o,
+                                                               (const CA_AS(1) char*)(obst_idx_s + (size_t)a_o * S * N + i_o),
+                                                               (const CA_AS(1) char*)nb_idx_s + ((size_t)a_o * K * N + i_o) * (CA_NBW16(BS) ? 2 : 1), N,
+                                                               cnts_o >> 8, cnts_o & 0xFF, (const CA_AS(3) char*)(s_px + (tid_o - i_o)), BS,
                                                                mk(s_px[tid_o], s_py[tid_o]), mk(s_vx[tid_o], s_vy[tid_o]), opt_fn(), rad_o,
                                                                1.0f / tho_o, 1.0f / th_o, 1.0f / dt_o, ms_o);
                     }
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
     int fail = nl;
     if (active) fail = lp2(ls, nl, p.max_speed, pref, false, nv);
     CA_STAMP(6);
-    if (active && fail < nl) lp3<KMAX + SMAX>(ls, nl, numObstLines, fail, p.max_speed, nv);
+    if (active && fail < nl) lp3<KMAX + SMAX>((__attribute__((address_space(3))) char*)ls.base, ls.stride, nl, numObstLines, fail, p.max_speed, nv);
     }
     if (active) {  // ---- integrate (App. A.1) ----
         vel = nv;
