@@ -1,5 +1,6 @@
 #!/bin/bash
-# quick A/B on the GPU box: the GPU suite (unless "bench" is given), then the three workloads' bench lines
+# quick check on the GPU box: tools/quick_check.sh <tag> [bench] -- the GPU suite (unless "bench" is given), then bench lines of C3 / C2 / C5 (full step and ORCA-only)
+# with their verified.bit_exact verdicts, under gpurun_out/<tag>/
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-q}; O=$R/gpurun_out/$T; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 if [ "$2" != bench ]; then
