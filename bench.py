@@ -363,11 +363,13 @@ def main():
         warm_run += 50 * chunk
         torch.cuda.synchronize()
     env.reset_stats()
-    # the kernel launches of every 8th step (short runs: every (steps // 5)-th) of the timed region carry a start and a stop
-    # event on their own dispatch (hipExtLaunchKernel inside the library, on the stream the kernels run on).  A sampled
-    # step still costs ~10 us of dispatch serialisation, so sampling every step would stretch the timed region by 8 %;
-    # the driver's --steps 20 brackets 5 steps (2 % of its region), the default run 250.
-    env.profile(1 if steps_per_launch > 1 else max(1, min(8, args.steps // 5)))
+    # The kernel launches of every 32nd step of the timed region (short runs: every (steps // 2)-th) carry a start and a stop event on
+    # their own dispatch (hipExtLaunchKernel inside the library, on the stream the kernels run on).  A sampled step costs ~10 us of
+    # dispatch serialisation (measured, round 5: sampling every step 119 us per step, every 8th 110.4, every 64th 109.3), so the
+    # default run brackets 62 of its 2000 steps (0.3 % of the region) and the driver's --steps 20 two (0.9 %).
+    # CA_BENCH_PROFILE_PERIOD overrides the period (diagnostic).
+    env.profile(int(os.environ["CA_BENCH_PROFILE_PERIOD"]) if "CA_BENCH_PROFILE_PERIOD" in os.environ else
+                (1 if steps_per_launch > 1 else max(1, min(32, args.steps // 2))))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -500,7 +502,11 @@ def main():
                          "traffic_detail": traffic_detail},
             "valu": valu,
             "kernels_ms": dict({k: round(v, 5) for k, v in kms_of.items()}, sum=round(sum(kms_of.values()), 5),
-                               wall_per_step=dt / args.steps * 1e3),
+                               wall_per_step=dt / args.steps * 1e3,
+                               sampled_launches={k: v[0] for k, v in ktimes.items() if v[0] > 0},
+                               note="mean duration of the SAMPLED launches (start / stop events on their own dispatch: such a launch is "
+                                    "serialised against its neighbours); unsampled launches overlap their ramp-up and drain with the "
+                                    "neighbouring kernels by a few tenths of a microsecond, so wall_per_step may lie slightly below the sum"),
             "full_step_algorithmic": {"bytes_per_agent": 316 if full else 52,
                                       "GB_per_s": agents * (316 if full else 52) / (dt / args.steps) / 1e9,
                                       "frac": agents * (316 if full else 52) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},

@@ -9,6 +9,6 @@ for rep in 1 2; do
   for v in product "$@"; do
     if [ $v = product ]; then lib=$R/collision_avoidance_amd/libcaenv.so; else lib=$R/variants/libcaenv_$v.so; fi
     timeout -k 10 300 python3 $R/tools/run_variant.py $lib --no-cpu-baseline $ARGS > $O/${v}_$rep.json 2>>$O/bench.err || { echo "$v failed"; tail -5 $O/bench.err; exit 1; }
-    python3 -c "import json;d=json.load(open('$O/${v}_$rep.json'));print('%-12s rep $rep %8.1f M  %s' % ('$v', d['value']/1e6, d['kernels_ms']))"
+    python3 -c "import json;d=json.load(open('$O/${v}_$rep.json'));print('%-12s rep $rep %8.1f M  %s' % ('$v', d['value']/1e6, {k:v for k,v in d['kernels_ms'].items() if isinstance(v,float)}))"
   done
 done

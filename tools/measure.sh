@@ -7,7 +7,7 @@ mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 timeout -k 10 900 python3 -m pytest $R/tests -m gpu -x -q > $O/${T}_gpu_tests.log 2>&1 || { tail -30 $O/${T}_gpu_tests.log; exit 1; }
 tail -1 $O/${T}_gpu_tests.log
 timeout -k 10 300 python3 $R/bench.py > $O/${T}_bench_C3_step.json 2>$O/bench.err || { tail $O/bench.err; exit 1; }
-python3 -c "import json;d=json.load(open('$O/${T}_bench_C3_step.json'));print('C3 step', d['value'], d['kernels_ms'], d['roofline']['kernel'], d['roofline']['frac'])"
+python3 -c "import json;d=json.load(open('$O/${T}_bench_C3_step.json'));print('C3 step', d['value'], {k:v for k,v in d['kernels_ms'].items() if isinstance(v,float)}, d['roofline']['kernel'], d['roofline']['frac'])"
 [ "$2" = quick ] && exit 0
 for wl in C2 C5; do timeout -k 10 300 python3 $R/bench.py --workload $wl > $O/${T}_bench_$wl.json 2>>$O/bench.err || exit 1; done
 # ORCA-only policy rollouts (BASELINE config C2 is one): ca_rollout in chunks of 50 steps, and one ca_orca_step per step
@@ -18,7 +18,7 @@ done
 python3 - <<PY
 import json,glob
 for f in sorted(glob.glob("$O/${T}_bench_*.json")):
-    d=json.load(open(f)); print("%-48s %8.1f M  %s" % (f.split("/")[-1], d["value"]/1e6, d["kernels_ms"]))
+    d=json.load(open(f)); print("%-48s %8.1f M  %s" % (f.split("/")[-1], d["value"]/1e6, {k:v for k,v in d["kernels_ms"].items() if isinstance(v,float)}))
 PY
 timeout -k 10 300 python3 $R/bench.py --variant free --no-cpu-baseline > $O/${T}_bench_C3_step_free.json 2>>$O/bench.err || exit 1
 timeout -k 10 300 python3 $R/bench.py --starts separated --no-cpu-baseline > $O/${T}_bench_C3_step_separated.json 2>>$O/bench.err || exit 1
