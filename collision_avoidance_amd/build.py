@@ -48,10 +48,12 @@ def hipcc():
 
 
 def is_stale():
+    """The library is missing, or was built from other sources / flags than the ones on disk: its compiled-in hash (CA_SRC_SHA,
+    what ca_source_sha() returns) is looked for in the file itself -- time stamps say nothing after a checkout."""
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(s) > t for s in SOURCES)
+    with open(LIB_PATH, "rb") as fh:
+        return source_sha().encode() not in fh.read()
 
 
 def build(force=False, verbose=False):

@@ -169,9 +169,6 @@ __device__ __forceinline__ bool lp1_reg(const float4 (&L)[ML], int no, float rad
             tLeft = (left & (tLeft < t)) ? t : tLeft;
             failed |= (par & (num < 0.0f)) | (!par & (tLeft > tRight));
         }
-#ifdef CA_LP1_SCHED_GROUP
-        if constexpr (j % CA_LP1_SCHED_GROUP == CA_LP1_SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
-#endif
     });
     if (failed) return false;
     const V2 opt = opt_fn();

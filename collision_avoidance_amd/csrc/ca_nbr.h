@@ -287,7 +287,8 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
         const unsigned lowmask = (unsigned)(P - 1);
         const unsigned top = __float_as_uint(rangeSq0);                  // a passing candidate's bits lie below it
         const unsigned span = 0xFFFFFFFFu >> p.logP;                     // images 0 .. span - 2 (the composite never is ~0)
-        const unsigned u0 = top - span + 1u;   // bit patterns up to u0 share image 0 (top >= span: neighbor_dist >= CA_MIN_LENGTH, ca_create)
+        // bit patterns up to u0 share image 0 (arenas of at most four lanes with a range below 1: every pattern fits, u0 = 0)
+        const unsigned u0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(top >= span ? top - span + 1u : 0u));
         unsigned ck[KMAX + 1];
 #pragma unroll
         for (int k = 0; k <= KMAX; ++k) ck[k] = (k < kofs) ? 0u : 0xFFFFFFFFu;
