@@ -171,6 +171,8 @@ class VecCollisionAvoidanceEnv:
                 (_lib.F_NODONE if no_done else 0)
         act_ptr = None
         if actions is not None:
+            if torch is not None and isinstance(actions, torch.Tensor):
+                actions = actions.detach().cpu().numpy()
             self._packed_act[...] = np.asarray(actions, np.float32).reshape(A, self.N)
             act_ptr = self._packed_act.ctypes.data
         self._call("ca_step_packed", self.h, act_ptr, flags, raw.ctypes.data, raw.nbytes)
