@@ -306,8 +306,17 @@ def main():
     coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     from collision_avoidance_amd import build as _b
-    if rank == 0 and not os.path.exists(_b.LIB_PATH):  # normally prebuilt by __graft_entry__.build()
+    if local == 0 and not os.path.exists(_b.LIB_PATH):  # normally prebuilt by __graft_entry__.build()
         _b.build()
+    oracle_error = None
+    if local == 0 and args.verify > 0:
+        # the checker's library is built by ONE process per node, before the barrier: N ranks calling make at once could
+        # write libca_oracle.so while another rank maps it (it too is normally prebuilt by __graft_entry__.build())
+        try:
+            from oracle import oracle as _o
+            _o.build()
+        except Exception as e:      # a box without make / g++: the measurement still stands, the verdict says why it is missing
+            oracle_error = "%s: %s" % (type(e).__name__, e)
     if dist is not None:
         dist.barrier()
     from collision_avoidance_amd import scenarios
@@ -378,6 +387,7 @@ def main():
     for i in range(args.steps):
         one_step(warm_run + i)
     torch.cuda.synchronize()
+    own_ns = int((time.perf_counter() - t0) * 1e9)     # this rank's K steps alone (reported per rank; never the job's time)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -398,13 +408,24 @@ def main():
         steps_run += n2
     verified = None
     if args.verify > 0:
-        verified = verify_against_oracle(env, args, w, p, scn, arena_offset, pool.cpu().numpy(), steps_run, steps_run - warm_run)
+        # outside the timed region; a checker that cannot run (no oracle library, an exception inside it) must not discard a
+        # measurement that completed: the line is printed with verified.bit_exact false + the error, and the exit code is non-zero
+        try:
+            if oracle_error is not None:
+                raise RuntimeError("oracle library could not be built: " + oracle_error)
+            verified = verify_against_oracle(env, args, w, p, scn, arena_offset, pool.cpu().numpy(), steps_run, steps_run - warm_run)
+        except Exception as e:
+            verified = {"arenas": 0, "first_global_arena": -1, "steps": steps_run, "timed_steps": steps_run - warm_run, "fields": 0,
+                        "bit_exact": False, "mismatch": None, "error": "%s: %s" % (type(e).__name__, e)}
 
     # THE collective of the job: one all_gather of the per-rank record -- statistics, device, and the rank's own time for the
     # timed region in nanoseconds (RCCL over xGMI when N > 1); the job's time is the maximum over the gathered records
     per_rank_stats, total_stats = cad.gather_stats(st, device=coll_dev, extra={
         "device": local, "dt_ns": int(dt * 1e9), "verified": -1 if verified is None else int(verified["bit_exact"]),
-        "verify_arena0": -1 if verified is None else verified["first_global_arena"]})
+        "verify_arena0": -1 if verified is None else verified["first_global_arena"], "warmup_steps_run": warm_run,
+        # the rank's own time for its K steps BEFORE the closing barrier (dt_ns includes the wait for the slowest rank, so it
+        # is nearly the same on every rank): this is the figure that shows which rank straggled
+        "own_ns": own_ns})
     dt = max(d["dt_ns"] for d in per_rank_stats) * 1e-9
     if rank == 0:
         agents = A * N
@@ -490,7 +511,12 @@ def main():
                        "sharding": "arenas, %d per GPU" % A},
             "world_size": world,
             "ranks": [{"rank": r, "device": d["device"], "agent_steps": d["agent_steps"], "verified": d["verified"],
-                       "verify_arena0": d["verify_arena0"]} for r, d in enumerate(per_rank_stats)],
+                       "verify_arena0": d["verify_arena0"], "dt_ns": d["dt_ns"], "own_ns": d["own_ns"],
+                       "warmup_steps_run": d["warmup_steps_run"],
+                       "agent_steps_per_s": d["agent_steps"] / max(1, d["own_ns"]) * 1e9} for r, d in enumerate(per_rank_stats)],
+            # slowest rank's own rate over the fastest's (1.0 = no straggler); from the per-rank times of the ONE all_gather
+            "efficiency": (min(d["agent_steps"] / max(1, d["own_ns"]) for d in per_rank_stats) /
+                           max(d["agent_steps"] / max(1, d["own_ns"]) for d in per_rank_stats)),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_low": traffic_low, "traffic_high": traffic_high,
@@ -541,7 +567,7 @@ def main():
                 pass
         print(json.dumps(out))
         if verified is not None and not out["verified"]["bit_exact"]:
-            raise SystemExit("bench.py: --verify FAILED: %s" % [verified["mismatch"]] + str([d["verified"] for d in per_rank_stats]))
+            raise SystemExit("bench.py: --verify FAILED: %s" % [verified.get("error") or verified["mismatch"]] + str([d["verified"] for d in per_rank_stats]))
     env.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -18,8 +18,20 @@ def __getattr__(name):
     raise AttributeError(name)
 
 
-try:  # the reference registers a gym id (collision_avoidance/__init__.py:3-6)
-    from gym.envs.registration import register as _register
-    _register(id='collision_avoidance-v0', entry_point='collision_avoidance_amd.envs:Collision_Avoidance_Env')
-except Exception:  # gym absent or id already registered
-    pass
+def _register_gym_id():
+    """The reference registers a gym id on import (collision_avoidance/__init__.py:3-6; run_rllib.py:82 resolves it with
+    gym.make('collision_avoidance-v0')).  gym is optional here: without it nothing is registered; with it a failure to
+    register anything but "already registered" (a second import path of the same package) is raised, not swallowed."""
+    try:
+        from gym.envs.registration import register
+    except ImportError:
+        return False
+    try:
+        register(id='collision_avoidance-v0', entry_point='collision_avoidance_amd.envs:Collision_Avoidance_Env')
+    except Exception as e:       # gym.error.Error("Cannot re-register id: ...") in every gym version
+        if "register" not in str(e).lower():
+            raise
+    return True
+
+
+_register_gym_id()

@@ -109,15 +109,14 @@ class Collision_Avoidance_Env(*_bases):
         self._fill_obs(self.vec.step_packed(None, no_done=True)[0])
 
     def seed(self, seed=None):
-        # env.py:494-496 returns [seed]; here the seed also keys the spawn draws of later resets
+        # env.py:494-496 returns [seed]; here the seed also keys the spawn draws of later resets.  The handle is rebuilt
+        # with the new seed and the WHOLE state carried over (get_state / set_state: simulator state, targets, lists, and
+        # the counters that key the draws -- episode, re-goal count, arrival steps, step count)
         self._seed = 0 if seed is None else int(seed)
-        state = {f: self.vec.get(f) for f in range(_lib.FLD_REWARD)}
-        lists = {f: self.vec.get(f) for f in (_lib.FLD_NB_COUNT, _lib.FLD_NB_IDX, _lib.FLD_OBST_COUNT,
-                                              _lib.FLD_OBST_IDX, _lib.FLD_AGENT_DONE, _lib.FLD_STEP_COUNT)}
+        state = self.vec.get_state()
         self.vec.close()
         self._make()
-        for f, v in list(state.items()) + list(lists.items()):
-            self.vec.set(f, v)
+        self.vec.set_state(state)
         return [seed]
 
     def render(self, mode='human'):

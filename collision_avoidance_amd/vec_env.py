@@ -94,6 +94,11 @@ class VecCollisionAvoidanceEnv:
 
     def close(self):
         self.__dict__.pop("_host_bufs", None); self.__dict__.pop("_packed", None); self.__dict__.pop("_packed_act", None)
+        for arr in self.__dict__.pop("_host_arrays", []):     # their memory goes with the handle (see host_array)
+            try:
+                arr.flags.writeable = False
+            except Exception:
+                pass
         if getattr(self, "h", None):
             self.L.ca_destroy(self.h)
             self.h = None
@@ -136,13 +141,18 @@ class VecCollisionAvoidanceEnv:
         return out
 
     def host_array(self, shape, dtype):
-        """A numpy array over page-locked, device-visible host memory from the library (ca_host_alloc: no PyTorch involved);
-        owned by the handle, released by close()."""
+        """A numpy array over page-locked, device-visible host memory from the library (ca_host_alloc: no PyTorch involved).
+        LIFETIME: the memory belongs to the handle and is released by close() (ca_destroy); the array -- and every view of it,
+        which is what host_buffer(), step(copy=False) and step_packed() hand out -- must not be touched after close().
+        Copy what has to outlive the environment (np.array(view)); close() marks the arrays it still knows read-only
+        as a tripwire for late writers."""
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         ptr = C.c_void_p()
         self._call("ca_host_alloc", self.h, max(n, 1), C.byref(ptr))
         buf = (C.c_char * max(n, 1)).from_address(ptr.value)
-        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self.__dict__.setdefault("_host_arrays", []).append(arr)
+        return arr
 
     def host_buffer(self, field):
         """A persistent page-locked host array for a field (a pageable destination takes the 67-MB observation of 4096 x 64
@@ -157,7 +167,8 @@ class VecCollisionAvoidanceEnv:
 
     def step_packed(self, actions=None, with_obs=True, stats=False, autoreset=False, no_done=False):
         """One host-side step in one round trip (ca_step_packed): actions [A,N] (None: the ORCA-only step) in, (obs, rewards, dones,
-        step_counts) out as views of ONE page-locked buffer owned by the environment, valid until the next call.  The form for one
+        step_counts) out as views of ONE page-locked buffer owned by the environment, valid until the next call and never after
+        close() (host_array: the buffer is freed with the handle).  The form for one
         environment per worker with results on the host every step (run_rllib.py:77, 108)."""
         an, A = self.A * self.N, self.A
         if "_packed" not in self.__dict__:
@@ -212,8 +223,13 @@ class VecCollisionAvoidanceEnv:
         if shape != [self.A, self.N, self.K, self.S, self.n_actions]:
             raise ValueError("set_state: the state is of an environment of shape %s, this one is %s"
                              % (shape, [self.A, self.N, self.K, self.S, self.n_actions]))
+        optional = ("REWARD", "ALAN_ACTION")   # joined in round 5: older snapshots restore without them; anything else
+        need = [n for n in self._STATE_FIELDS if n not in optional] + (["ALAN_WEIGHTS", "ALAN_TIMES"] if self.n_actions > 0 else [])
+        missing = [n for n in need if n not in st]
+        if missing:                            # missing is a truncated / corrupt snapshot: nothing is restored
+            raise KeyError("set_state: the snapshot lacks %s" % ", ".join(missing))
         for name in self._STATE_FIELDS:
-            if name in st:      # (REWARD joined in round 5: older snapshots restore without it)
+            if name in st:
                 self.set(getattr(_lib, "FLD_" + name), st[name])
         if self.n_actions > 0:
             self.set(_lib.FLD_ALAN_WEIGHTS, st["ALAN_WEIGHTS"])

@@ -57,6 +57,16 @@ def test_gloo_ranks_drive_the_hip_library(world, arenas):
     a0 = [r["verify_arena0"] for r in job["ranks"]]
     assert all(r * arenas <= a < (r + 1) * arenas for r, a in enumerate(a0)), a0
     assert [s["ranks"][0]["verify_arena0"] for s in singles] == a0     # a single process playing rank r checks the same block
+    # the line explains itself per rank: each rank's own time for its K steps (before the closing barrier), its time including the
+    # barrier (what the job's time is the maximum of), the warm-up it really ran, and the slowest-over-fastest ratio -- all from the
+    # ONE all_gather (no further collective)
+    for r in job["ranks"]:
+        assert 0 < r["own_ns"] <= r["dt_ns"] and r["warmup_steps_run"] == WARM, r
+        assert abs(r["agent_steps_per_s"] - r["agent_steps"] / r["own_ns"] * 1e9) <= 1e-6 * r["agent_steps_per_s"]
+    assert abs(max(r["dt_ns"] for r in job["ranks"]) * 1e-6 / STEPS - job["ms_per_step"]) <= 1e-9 * job["ms_per_step"] + 1e-12
+    rates = [r["agent_steps_per_s"] for r in job["ranks"]]
+    assert 0 < job["efficiency"] <= 1 and abs(job["efficiency"] - min(rates) / max(rates)) < 1e-9
+    assert job["collectives"]["job"].startswith("one all_gather")
     # every rank ran the HIP kernels: the launch geometry is that of its shard; the line names the code that ran
     assert job["launch"] == singles[0]["launch"]
     assert job["src_sha"] == singles[0]["src_sha"] == job["src_sha_on_disk"] != "unknown"
