@@ -24,7 +24,7 @@ EXPORTS = ("ca_create", "ca_destroy", "ca_last_error", "ca_set_stream", "ca_set_
            "ca_get_stats", "ca_reset_stats", "ca_sync", "ca_debug_math", "ca_profile", "ca_profile_read", "ca_launch_info",
            "ca_alan_configure", "ca_alan_step", "ca_alan_rollout", "ca_reset_masked", "ca_get_obstacles",
            "ca_set_obstacles_per_arena", "ca_get_obstacles_arena", "ca_solver_info", "ca_source_sha", "ca_host_alloc", "ca_host_free",
-           "ca_step_packed")
+           "ca_step_packed", "ca_allow_obstacle_overflow")
 
 
 class Config(C.Structure):
@@ -100,6 +100,7 @@ def load():
     L.ca_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.ca_reset_stats.argtypes = [vp]
     L.ca_sync.argtypes = [vp]
+    L.ca_allow_obstacle_overflow.argtypes = [vp, i32]
     L.ca_debug_math.argtypes = [vp, i32, vp, vp, i32]
     L.ca_profile.argtypes = [vp, i32]
     L.ca_profile_read.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_float)]

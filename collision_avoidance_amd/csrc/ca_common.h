@@ -41,6 +41,8 @@ struct StepCold {
     unsigned long long* arena_stats;  // [A][8]
     unsigned long long* arena_steps;  // [A] steps this arena was ADVANCED by a solve kernel (counted in the kernel by the
                                       // arena's owner lane: the evidence of work behind ca_stats.agent_steps)
+    unsigned long long* ovf_word;     // page-locked HOST word the device writes: the last obstacle-neighbour list that overflowed
+                                      // (note_overflow below); the host turns it into the handle's sticky CA_ERANGE status
     double reward_scale;
     uint64_t seed;
     int64_t arena_offset;
@@ -98,6 +100,16 @@ struct StepArgs {
     uint32_t flags;
     float time_step, neighbor_dist, time_horizon, time_horizon_obst, radius, max_speed;
 };
+
+// An obstacle-neighbour list met more edges in range than it holds: RVO2 keeps them all (env.py:249, 301-318), here the
+// farthest are dropped.  Counted per arena (ST_OVERFLOW) by the callers; this makes it LOUD: (global arena, agent, edges in
+// range) go to a host-visible word that the next call on the handle -- or its next synchronisation -- reports as CA_ERANGE
+// unless the caller opted in (ca_allow_obstacle_overflow).  Rare by construction: a scalar load and one store.
+__device__ __forceinline__ void note_overflow(const StepCold* cold, int a, int i, int oin) {
+    const unsigned long long g = (unsigned long long)(cold->arena_offset + (int64_t)a) & 0xFFFFFFFFFFull;
+    const unsigned long long v = (1ull << 63) | (g << 20) | ((unsigned long long)(i & 0x7FF) << 8) | (unsigned long long)(oin > 255 ? 255 : oin);
+    __hip_atomic_store(cold->ovf_word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 enum { ST_EPISODES = 0, ST_COLL = 1, ST_OBST_COLL = 2, ST_GOALS = 3, ST_OVERFLOW = 4, ST_SUMREW = 5, ST_FROZEN = 6, ST_LASTEP = 7, ST_STRIDE = 8 };
 

@@ -65,6 +65,10 @@ struct ca_env {
     std::vector<int> h_tab_off;      // empty: one table for all arenas; else [A + 1] offsets into h_obst
     int* d_tab_off = nullptr;
     StepCold* d_cold = nullptr;      // the epilogue's arguments (ca_common.h)
+    // obstacle-neighbour overflow made loud: a page-locked host word the kernels write (ca_common.h note_overflow); unless the
+    // caller opted in (ca_allow_obstacle_overflow) it is the handle's sticky CA_ERANGE status (overflow_status below)
+    unsigned long long* ovf_host = nullptr;
+    bool allow_overflow = false;
     int* d_order = nullptr;          // [grid] block order of the solve kernel (null: identity)
     int P = 1, logP = 0, BS = 64, grid = 1, K = 0, S = 1;
     bool obs_dense_on = false;
@@ -115,6 +119,24 @@ static int fail(ca_env* e, int code, const char* fmt, ...) {
         hipError_t _r = (call);                                                                 \
         if (_r != hipSuccess) return fail(e, CA_EHIP, "%s failed: %s", #call, hipGetErrorString(_r)); \
     } while (0)
+
+// RVO2 keeps EVERY obstacle edge in range of an agent (env.py:249, 301-318 iterate them all); the lists here hold
+// max_obst_neighbors (<= CA_MAX_OBST_NEIGHBORS) and drop the farthest beyond that -- a deviation that must not pass silently.
+// The kernels report the last overflow through a host-visible word; every call that advances the environment returns
+// CA_ERANGE from then on (like a sticky device error: the call AFTER the kernel that overflowed has finished sees it, and the
+// calls that synchronise -- ca_sync, ca_step_packed -- see it at once), until ca_reset_stats clears it or the caller accepts
+// the truncation with ca_allow_obstacle_overflow(env, 1).  ca_get / ca_get_stats keep working (obst_overflow counts).
+static int overflow_status(ca_env* e, const char* where) {
+    if (e->allow_overflow || !e->ovf_host) return CA_OK;
+    const unsigned long long v = *(volatile unsigned long long*)e->ovf_host;
+    if (!(v >> 63)) return CA_OK;
+    return fail(e, CA_ERANGE, "%s: an obstacle-neighbour list overflowed: arena %lld, agent %d had %d%s obstacle edges in range but "
+                "max_obst_neighbors=%d, so the farthest were dropped (RVO2 keeps every edge in range: collision_avoidence_env.py:249, "
+                "301-318).  Raise max_obst_neighbors (at most %d), coarsen the world's polylines, or accept the truncation with "
+                "ca_allow_obstacle_overflow(env, 1); ca_reset_stats clears this status", where,
+                (long long)((v >> 20) & 0xFFFFFFFFFFull), (int)((v >> 8) & 0x7FF), (int)(v & 0xFF), (v & 0xFF) == 255 ? "+" : "",
+                e->S, CA_MAX_OBST_NEIGHBORS);
+}
 
 enum { KIND_NBR = 0, KIND_STEP = 1, KIND_OBS = 2, KIND_RESET = 3 };
 enum { CA_ROLLOUT_MAX_T = 256 };  // steps per launch of the one-launch rollout (ca_rollout)  // KIND_RESET also times the small ALAN kernels
@@ -218,7 +240,7 @@ static void fill_cold(const ca_env* e, StepCold& c) {
     c.orient_x = e->orient_x; c.orient_y = e->orient_y;
     c.agent_done = e->agent_done; c.arrive_step = e->arrive_step; c.regoal_count = e->regoal_count;
     c.step_count = e->step_count; c.arena_done = e->arena_done; c.episode = e->episode;
-    c.arena_stats = e->arena_stats; c.arena_steps = e->arena_steps;
+    c.arena_stats = e->arena_stats; c.arena_steps = e->arena_steps; c.ovf_word = e->ovf_host;
     c.reward_scale = g.reward_scale; c.seed = g.seed; c.arena_offset = g.arena_offset;
     c.max_step = g.max_step; c.done_mode = g.done_mode; c.done_x_thresh = g.done_x_thresh;
     c.spawn_x0 = g.spawn_x0; c.spawn_x1 = g.spawn_x1; c.spawn_y0 = g.spawn_y0; c.spawn_y1 = g.spawn_y1;
@@ -614,11 +636,13 @@ static void pick_variant(ca_env* e) {
 // the dynamic-LDS limits of the kernels pick_variant chose -- and, for BOTH callers (ca_create, and install_tables whenever a
 // world is installed and the variant may change), the check that the chosen kernel fits the CU's 160 KiB: the lane kernels by
 // their dynamic part + the statically declared arrays of the fused neighbour search, the two-lanes kernel by what the
-// compiled kernel itself reports (hipFuncGetAttributes).  hipErrorInvalidValue = does not fit (the callers turn it into CA_ERANGE).
+// compiled kernel itself reports (hipFuncGetAttributes).  *misfit = the kernel does not fit (the callers turn it into CA_ERANGE);
+// the return value carries genuine HIP failures only.
 static const size_t LDS_PER_CU = 160 * 1024;
-static hipError_t apply_variant_attributes(ca_env* e) {
+static hipError_t apply_variant_attributes(ca_env* e, bool* misfit) {
     hipError_t r = hipSuccess;
-    if (!e->pair && e->lds + lds_static_bytes(e) > LDS_PER_CU) return hipErrorInvalidValue;
+    *misfit = false;
+    if (!e->pair && e->lds + lds_static_bytes(e) > LDS_PER_CU) { *misfit = true; return hipSuccess; }
     if (r == hipSuccess && e->pair) {
         const void* f = e->KT == 5 ? (e->BS == 256 ? reinterpret_cast<const void*>(&pair_kernel<5, 256>)
                                                    : reinterpret_cast<const void*>(&pair_kernel<5, 512>))
@@ -626,7 +650,7 @@ static hipError_t apply_variant_attributes(ca_env* e) {
                                                    : reinterpret_cast<const void*>(&pair_kernel<10, 512>));
         hipFuncAttributes fa;
         r = hipFuncGetAttributes(&fa, f);
-        if (r == hipSuccess && fa.sharedSizeBytes + e->lds_p > LDS_PER_CU) return hipErrorInvalidValue;
+        if (r == hipSuccess && fa.sharedSizeBytes + e->lds_p > LDS_PER_CU) { *misfit = true; return hipSuccess; }
         if (r == hipSuccess) r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_p);
     }
     if (r == hipSuccess && e->help && e->lds > 48 * 1024) {
@@ -812,7 +836,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
     if (r == hipSuccess) r = dalloc(e, &e->dbg_obs, (size_t)cfg->n_arenas * ((cfg->n_agents + 15) / 16 + 16) * 4 * 16);
 #endif
     bool lds_misfit = false;
-    if (r == hipSuccess) { r = apply_variant_attributes(e); lds_misfit = r == hipErrorInvalidValue; }
+    if (r == hipSuccess) r = apply_variant_attributes(e, &lds_misfit);
     if (r == hipSuccess && e->quad_roll && e->lds_q > 48 * 1024)
         r = hipFuncSetAttribute(quad_fn(e), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_q);
     if (r == hipSuccess) {
@@ -823,6 +847,10 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ol);
         }
     }
+    if (r == hipSuccess) {
+        r = hipHostMalloc((void**)&e->ovf_host, sizeof(unsigned long long), hipHostMallocDefault);
+        if (r == hipSuccess) *e->ovf_host = 0ull;
+    }
     if (r == hipSuccess) r = hipMalloc((void**)&e->d_cold, sizeof(StepCold));
     if (r == hipSuccess) {
         StepCold hc;
@@ -830,7 +858,7 @@ int ca_create(const ca_config* cfg, int device, void* stream, ca_env** out) {
         r = upload(e, e->d_cold, &hc, sizeof hc);
     }
     if (r == hipSuccess) r = hipStreamSynchronize(e->stream);  // the zero fills are done before the handle is handed out
-    if (lds_misfit) {
+    if (r == hipSuccess && lds_misfit) {
         fail(nullptr, CA_ERANGE, "ca_create: the solve kernel for n_agents=%d, max_neighbors=%d, max_obst_neighbors=%d does not fit the "
              "160 KiB of LDS of a CU", cfg->n_agents, e->K, e->S);
         ca_destroy(e);
@@ -857,6 +885,7 @@ int ca_destroy(ca_env* e) {
                     e->alan_w, e->alan_t, e->alan_dirs, e->alan_u, e->alan_action, e->d_alan, e->mask_buf};
     for (void* b : bufs) if (b) hipFree(b);
     for (const auto& h : e->host_allocs) hipHostFree(h.first);
+    if (e->ovf_host) hipHostFree(e->ovf_host);
     for (const ca_env::Span& sp : e->spans) { hipEventDestroy(sp.t0); hipEventDestroy(sp.t1); }
     for (hipEvent_t ev : e->free_events) hipEventDestroy(ev);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
@@ -945,25 +974,35 @@ static int install_tables(ca_env* e, std::vector<ObstDev>& all, std::vector<int>
         if (n_off) hipFree(n_off);
         return fail(e, CA_EHIP, "ca_set_obstacles: %s (the previous tables stay installed)", hipGetErrorString(r));
     }
+    // the solve-kernel variant depends on the size of the world (pick_variant): the variant the NEW world selects is chosen and
+    // checked against the CU's LDS while the old tables are still installed; a world whose kernel does not fit leaves the
+    // handle exactly as it was (tables, variant, ALAN form)
+    int me = 0;
+    if (offs.empty()) me = (int)all.size();
+    else for (size_t a = 0; a + 1 < offs.size(); ++a) me = std::max(me, offs[a + 1] - offs[a]);
+    struct { int ST, SMX, KT, max_edges; bool help, pair; size_t lds, lds_p; } old_v = {e->ST, e->SMX, e->KT, e->max_edges, e->help, e->pair, e->lds, e->lds_p};
+    e->max_edges = me;
+    pick_variant(e);
+    bool misfit = false;
+    const hipError_t ra = apply_variant_attributes(e, &misfit);
+    if (misfit || ra != hipSuccess) {
+        e->ST = old_v.ST; e->SMX = old_v.SMX; e->KT = old_v.KT; e->max_edges = old_v.max_edges; e->help = old_v.help; e->pair = old_v.pair;
+        e->lds = old_v.lds; e->lds_p = old_v.lds_p;
+        bool dummy = false;
+        (void)apply_variant_attributes(e, &dummy);   // (the previous variant's limits again: the attribute calls are idempotent)
+        hipFree(n_obst);
+        if (n_off) hipFree(n_off);
+        if (misfit)
+            return fail(e, CA_ERANGE, "ca_set_obstacles: the solve kernel this world selects does not fit the 160 KiB of LDS of a CU "
+                        "(n_agents=%d, max_neighbors=%d, max_obst_neighbors=%d); the previous tables stay installed", e->cfg.n_agents, e->K, e->S);
+        return fail(e, CA_EHIP, "ca_set_obstacles: %s (the previous tables stay installed)", hipGetErrorString(ra));
+    }
     if (e->d_obst) hipFree(e->d_obst);
     if (e->d_tab_off) hipFree(e->d_tab_off);
     e->d_obst = n_obst;
     e->d_tab_off = n_off;
     e->h_obst.swap(all);
     e->h_tab_off.swap(offs);
-    // the solve-kernel variant depends on the size of the world (pick_variant)
-    int me = 0;
-    if (e->h_tab_off.empty()) me = (int)e->h_obst.size();
-    else for (size_t a = 0; a + 1 < e->h_tab_off.size(); ++a) me = std::max(me, e->h_tab_off[a + 1] - e->h_tab_off[a]);
-    e->max_edges = me;
-    pick_variant(e);
-    {
-        const hipError_t ra = apply_variant_attributes(e);
-        if (ra == hipErrorInvalidValue)
-            return fail(e, CA_ERANGE, "ca_set_obstacles: the solve kernel this world selects does not fit the 160 KiB of LDS of a CU "
-                        "(n_agents=%d, max_neighbors=%d, max_obst_neighbors=%d)", e->cfg.n_agents, e->K, e->S);
-        HIPCHK(e, ra);
-    }
     return alan_pick(e);   // (the form of the ALAN step follows the solve kernel)
 }
 
@@ -1377,6 +1416,7 @@ int ca_reset_masked(ca_env* e, const int32_t* mask, int32_t mask_is_device, uint
 }
 
 static int do_step(ca_env* e, const float* actions, uint32_t flags) {
+    { const int rs = overflow_status(e, "step"); if (rs) return rs; }
     if (e->prof_period > 1) e->profiling = (e->steps_done % (uint64_t)e->prof_period) == 0;
     StepArgs a;
     fill_args(e, a, actions, flags);
@@ -1438,7 +1478,7 @@ int ca_step_packed(ca_env* e, const float* actions_host, uint32_t flags, void* o
         HIPCHK(e, hipMemcpyAsync(out + obs_b, e->reward, rest_b, hipMemcpyDeviceToHost, e->stream));
     }
     HIPCHK(e, hipStreamSynchronize(e->stream));   // (also the point from which the caller may reuse its action buffer)
-    return CA_OK;
+    return overflow_status(e, "ca_step_packed");       // (this very step's lists included: the stream is idle)
 }
 
 int ca_orca_step(ca_env* e, uint32_t flags) {
@@ -1491,6 +1531,7 @@ int ca_alan_step(ca_env* e, const double* u, int32_t u_is_device, uint32_t flags
     if (flags & (CA_F_AUTORESET | CA_F_NODONE))
         return fail(e, CA_EINVAL, "ca_alan_step: CA_F_AUTORESET / CA_F_NODONE do not apply (ALAN:106-123)");
     HIPCHK(e, hipSetDevice(e->device));
+    { const int rs = overflow_status(e, "ca_alan_step"); if (rs) return rs; }
     if (u && !u_is_device) {  // stage the caller's host uniforms
         HIPCHK(e, hipMemcpyAsync(e->alan_u, u, AN(e) * 8, hipMemcpyHostToDevice, e->stream));
         HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1540,6 +1581,7 @@ int ca_alan_step(ca_env* e, const double* u, int32_t u_is_device, uint32_t flags
 
 int ca_alan_rollout(ca_env* e, int32_t steps, uint32_t flags) {
     if (!e || steps < 0) return fail(e, CA_EINVAL, "ca_alan_rollout: bad argument");
+    { const int rs = overflow_status(e, "ca_alan_rollout"); if (rs) return rs; }
     if (e->n_actions > 0 && e->alan_fused && e->quad_roll && !(flags & (CA_F_OBS | CA_F_AUTORESET | CA_F_NODONE)) && steps > 1) {
         // run_sim(mode=1) (ALAN:106-123) as ONE launch per CA_ROLLOUT_MAX_T steps: select -> doStep -> update for every step
         // inside the four-lanes kernel, weights and times resident in LDS (ca_quad.h)
@@ -1579,6 +1621,7 @@ int ca_observe(ca_env* e) {
 int ca_rollout(ca_env* e, int32_t steps, uint32_t flags) {
     if (!e || steps < 0) return fail(e, CA_EINVAL, "ca_rollout: bad argument");
     HIPCHK(e, hipSetDevice(e->device));
+    { const int rs = overflow_status(e, "ca_rollout"); if (rs) return rs; }
     if (e->quad_roll && !(flags & CA_F_OBS) && steps > 1) {
         // ONE launch per CA_ROLLOUT_MAX_T steps: the workgroup that owns an arena keeps it in registers / LDS for all of
         // them (ca_quad.h).  Bounded, so that a long rollout stays a sequence of kernels of a few milliseconds (a kernel
@@ -1605,6 +1648,12 @@ int ca_sync(ca_env* e) {
     if (!e) return CA_EINVAL;
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    return overflow_status(e, "ca_sync");
+}
+
+int ca_allow_obstacle_overflow(ca_env* e, int32_t allow) {
+    if (!e) return CA_EINVAL;
+    e->allow_overflow = allow != 0;
     return CA_OK;
 }
 
@@ -1642,6 +1691,10 @@ int ca_reset_stats(ca_env* e) {
     HIPCHK(e, hipMemsetAsync(e->arena_stats, 0, (size_t)e->cfg.n_arenas * ST_STRIDE * 8, e->stream));
     HIPCHK(e, hipMemsetAsync(e->arena_steps, 0, (size_t)e->cfg.n_arenas * 8, e->stream));
     e->steps_done = 0;
+    if (e->ovf_host && (*(volatile unsigned long long*)e->ovf_host >> 63)) {   // the sticky overflow status goes with the counters; a step
+        HIPCHK(e, hipStreamSynchronize(e->stream));                              // still in flight must not set it again behind the clear
+        *(volatile unsigned long long*)e->ovf_host = 0ull;
+    }
     return CA_OK;
 }
 

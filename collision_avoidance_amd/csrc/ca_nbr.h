@@ -345,7 +345,10 @@ __device__ __forceinline__ bool nbr_body(const StepArgs& p) {
 
     CA_STAMP(14);
     if (active) {
-        if (oin > S) atomicAdd(reinterpret_cast<int*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_OVERFLOW]), 1);
+        if (__builtin_expect(oin > S, 0)) {
+            atomicAdd(reinterpret_cast<int*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_OVERFLOW]), 1);
+            note_overflow(p.cold, a, i, oin);
+        }
         p.counts[q] = (unsigned short)(ncnt | (ocnt << 8));
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)

@@ -390,7 +390,10 @@ __global__ __launch_bounds__(2 * BS, 4) void pair_kernel(const StepArgs p) {
     CA_PSTAMP(4);
     // ---- the lists are state (the reference's reset() observes with the lists of the last doStep) ----
     if (active) {
-        if (oin > S && h == 0) atomicAdd(reinterpret_cast<int*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_OVERFLOW]), 1);
+        if (__builtin_expect(oin > S && h == 0, 0)) {
+            atomicAdd(reinterpret_cast<int*>(&p.arena_stats[(size_t)a * ST_STRIDE + ST_OVERFLOW]), 1);
+            note_overflow(p.cold, a, i, oin);
+        }
         if (h == 0) p.counts[q] = (unsigned short)(ncnt | (ocnt << 8));
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)

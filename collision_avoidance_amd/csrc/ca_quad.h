@@ -332,7 +332,7 @@ __global__ __launch_bounds__(BS) void quad_kernel(const StepArgs p) {
         merge_quad<SQ>(okey);
         oin = quad_sum(oin);
         const int ocnt = oin < S ? oin : S;
-        if (oin > S && q == 0) acc_ovf += 1;
+        if (__builtin_expect(oin > S && q == 0, 0)) { acc_ovf += 1; note_overflow(p.cold, a, i, oin); }
 
 #if !defined(CA_STAMPS) || CA_STAMPS != 3
         CA_STAMP(2);

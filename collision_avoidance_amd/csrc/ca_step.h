@@ -483,7 +483,12 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
         if ((tid & 63) == 63) atomicMax(&s_vmax2, sp);
     }
     __syncthreads();  // every lane is done with the pre-step arena image
-    s_px[tid] = pos.x; s_py[tid] = pos.y;
+    // the post-step positions, staged for the pair count below.  Arenas within one wave (!LISTP): as (x, y) pairs, TWICE per
+    // arena -- entries [2 lbase + i] and [2 lbase + N + i] of the float2 view of the four staged arrays --, so that the balanced
+    // scan reads "agent (i + d) mod N" as entry i + d without a wrap
+    float2* s_xy2 = reinterpret_cast<float2*>(s_px);
+    if constexpr (LISTP) { s_px[tid] = pos.x; s_py[tid] = pos.y; }
+    else if (i < p.N && la < apb) { s_xy2[2 * lbase + i] = make_float2(pos.x, pos.y); s_xy2[2 * lbase + i + p.N] = make_float2(pos.x, pos.y); }
     s_misc[tid * 4 + 0] = 0; s_misc[tid * 4 + 1] = 0; s_misc[tid * 4 + 2] = 0; s_misc[tid * 4 + 3] = 0;
     __syncthreads();
     int* red = s_misc + la * 4;  // per-arena: [0] not-done agents, [1] pairs, [2] wall hits, [3] goals
@@ -523,10 +528,24 @@ __global__ __launch_bounds__(BS * HELP, ST > 0 ? (BS == 512 ? CA_LB512 : 4) : 1)
             });
             scan_all = (ncnt == K) && !(far2 > sqr(R + R + 2.0f * m2));
         }
-        if (__ballot(scan_all) != 0ull && scan_all) {
-            pairs = 0;
-            for (int j = i + 1; j < N; ++j)
-                if (absSq(pos - mk(s_px[lbase + j], s_py[lbase + j])) < crSq) ++pairs;
+        if constexpr (LISTP) {
+            if (__ballot(scan_all) != 0ull && scan_all) {
+                pairs = 0;
+                for (int j = i + 1; j < N; ++j)
+                    if (absSq(pos - mk(s_px[lbase + j], s_py[lbase + j])) < crSq) ++pairs;
+            }
+        } else {
+            // Every unordered pair once, the same work for every lane: agent i tests the agents (i + d) mod N for d = 1 .. (N - 1) / 2,
+            // and, N even, the lower half also its antipode d = N / 2 -- N / 2 trips for every lane where the triangular loop
+            // `j = i + 1 .. N - 1` cost the WAVE N - 1 trips (lane 0's) for half the useful work.  (x - y)^2 = (y - x)^2 bit for bit, and the
+            // per-arena sum is an integer: the same totals.  Four candidates per trip through immediate offsets (the staging above).
+            const float2* xs = s_xy2 + (active ? 2 * lbase + i : 0);
+            const int H = (N - 1) >> 1;
+            auto near = [&](int d) __attribute__((always_inline)) { const float2 o = xs[d]; return absSq(pos - mk(o.x, o.y)) < crSq ? 1 : 0; };
+            int d = 1;
+            for (; d + 3 <= H; d += 4) pairs += near(d) + near(d + 1) + near(d + 2) + near(d + 3);
+            for (; d <= H; ++d) pairs += near(d);
+            if (!(N & 1) && N > 1) { const int h = N >> 1; if (i < h) pairs += near(h); }
         }
         if (active) {
             bool wall = false;

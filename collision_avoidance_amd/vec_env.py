@@ -36,10 +36,14 @@ class VecCollisionAvoidanceEnv:
     params:   dict of ca_config fields; defaults are the reference env's constants.
     use_torch: hand observations/rewards out as torch tensors on the device (zero-copy for the
                observation) and accept device tensors as actions.  False: numpy in/out.
+    allow_obst_overflow: the reference's simulator keeps every obstacle edge in range of an agent (env.py:249, 301-318); the
+               lists here hold max_obst_neighbors (<= 16).  False (default): an agent with more edges in range makes the step
+               calls raise (CA_ERANGE, naming arena and agent); True: the nearest max_obst_neighbors are kept and the event is
+               only counted (stats()["obst_overflow"]).
     """
 
     def __init__(self, n_arenas, n_agents, scenario="crowd", params=None, device=0, seed=0,
-                 arena_offset=0, max_obst_neighbors=None, use_torch=None, obstacles="scenario"):
+                 arena_offset=0, max_obst_neighbors=None, use_torch=None, obstacles="scenario", allow_obst_overflow=False):
         self.L = _lib.load()
         self.A, self.N = int(n_arenas), int(n_agents)
         p = scenarios.env_params()
@@ -66,6 +70,8 @@ class VecCollisionAvoidanceEnv:
         rc = self.L.ca_create(C.byref(self.cfg), self.device, None, C.byref(h))
         _lib.check(self.L, None, rc, "ca_create")
         self.h = h
+        if allow_obst_overflow:
+            self._call("ca_allow_obstacle_overflow", self.h, 1)
         if self.use_torch:
             # run on PyTorch's current stream (its handle is 0 for the default stream), so that
             # tensor ops and torch.cuda.Event order naturally with the environment's kernels

@@ -31,7 +31,9 @@ extern "C" {
 #define CA_N_RAYS 16
 #define CA_MAX_NEIGHBORS 16      /* largest supported max_neighbors       */
 #define CA_MAX_OBST_NEIGHBORS 16 /* largest supported max_obst_neighbors: RVO2 keeps every edge in range (env.py:249,
-                                    301-318); 16 covers the reference's own worlds (ca_stats.obst_overflow counts the rest) */
+                                    301-318); 16 covers the reference's own worlds.  A list that meets more edges in range
+                                    than it holds drops the farthest, counts it (ca_stats.obst_overflow) AND makes every
+                                    later step call fail with CA_ERANGE: see ca_allow_obstacle_overflow */
 #define CA_MAX_AGENTS 1024       /* one workgroup owns one arena; above 256 agents max_neighbors <= 10
                                     is required (LDS capacity: the register-line solve kernels)         */
 
@@ -132,7 +134,8 @@ typedef struct ca_config {
     float radius;               /* env.py:31                                                  */
     float max_speed;            /* env.py:32                                                  */
     int32_t max_obst_neighbors; /* capacity of the obstacle-neighbour list, 1..CA_MAX_OBST_NEIGHBORS;
-                                   overflow is counted in ca_stats.obst_overflow               */
+                                   overflow is counted in ca_stats.obst_overflow and is an error
+                                   (CA_ERANGE) unless ca_allow_obstacle_overflow accepted it    */
     int32_t max_step;           /* env.py:44; <= 0: no cap                                    */
     int32_t done_mode;
     float done_x_thresh;        /* env.py:359                                                 */
@@ -252,6 +255,17 @@ int ca_alan_step(ca_env* env, const double* u, int32_t u_is_device, uint32_t fla
  * (ca_solver_info: rollout_one_launch) the bandit runs INSIDE that kernel -- one launch per 256 steps, weights and times
  * resident in LDS --, and a single ca_alan_step is one launch instead of three (select, solve, update). */
 int ca_alan_rollout(ca_env* env, int32_t steps, uint32_t flags);
+
+/* The reference's simulator keeps EVERY obstacle edge within range of an agent (sim.getAgentNumObstacleNeighbors /
+ * getAgentObstacleNeighbor, env.py:249, 301-318, iterate them all); this library's lists hold max_obst_neighbors and drop the
+ * farthest edges beyond that.  So that such a deviation cannot pass unnoticed, an overflow is a sticky error of the handle:
+ * once a step has met an agent with more edges in range than the list holds, ca_step / ca_step_host / ca_step_packed /
+ * ca_orca_step / ca_rollout / ca_alan_step / ca_alan_rollout and ca_sync return CA_ERANGE (ca_last_error names the global arena,
+ * the agent and the number of edges) -- asynchronously, like a device fault: the first call made after the kernel that
+ * overflowed has finished reports it, calls that synchronise report it at once -- until ca_reset_stats clears it.
+ * ca_allow_obstacle_overflow(env, 1) accepts the truncation (nearest max_obst_neighbors edges kept, counted in
+ * ca_stats.obst_overflow and per arena); 0 restores the default.  ca_get / ca_get_stats always work. */
+int ca_allow_obstacle_overflow(ca_env* env, int32_t allow);
 
 /* Blocks until the stream is idle, then returns the counters accumulated so far. */
 int ca_get_stats(ca_env* env, ca_stats* out);

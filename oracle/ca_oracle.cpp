@@ -223,12 +223,50 @@ void compute_neighbors(Arena& a, const std::vector<ObstVertex>& obst, int i, int
     }
 }
 
+/* ---- diagnostics for tests/test_oracle_orca_definition.py: which branch of App. A.3 / A.4 / A.5 an agent-step took, and the
+ * ORCA lines it built.  Thread-local (a shared counter written for every agent-step would serialise the multi-core
+ * baseline on one cache line); a branch costs one increment.  Read through orc_debug_branches / orc_debug_capture_*. */
+#define ORC_BRANCHES(X)                                                                                                   \
+    X(OBST_EDGE) X(OBST_COVERED) X(OBST_COLL_LEFT_VERTEX) X(OBST_COLL_LEFT_VERTEX_NONCONVEX) X(OBST_COLL_RIGHT_VERTEX)    \
+    X(OBST_COLL_RIGHT_VERTEX_SKIPPED) X(OBST_COLL_SEGMENT) X(OBST_OBLIQUE_LEFT) X(OBST_OBLIQUE_LEFT_NONCONVEX)            \
+    X(OBST_OBLIQUE_RIGHT) X(OBST_OBLIQUE_RIGHT_NONCONVEX) X(OBST_LEGS_USUAL) X(OBST_LEFT_LEG_NONCONVEX)                   \
+    X(OBST_RIGHT_LEG_NONCONVEX) X(OBST_LEFT_LEG_FOREIGN) X(OBST_RIGHT_LEG_FOREIGN) X(OBST_PROJ_LEFT_CIRCLE)               \
+    X(OBST_PROJ_RIGHT_CIRCLE) X(OBST_PROJ_CUTOFF) X(OBST_PROJ_LEFT_LEG) X(OBST_PROJ_LEFT_LEG_FOREIGN_SKIPPED)             \
+    X(OBST_PROJ_RIGHT_LEG) X(OBST_PROJ_RIGHT_LEG_FOREIGN_SKIPPED) X(AGENT_CUTOFF_CIRCLE) X(AGENT_LEG_LEFT)                \
+    X(AGENT_LEG_RIGHT) X(AGENT_COLLISION) X(LP2_OPT_INSIDE_DISC) X(LP2_OPT_CLAMPED) X(LP2_DIR_OPT) X(LP2_LINE_SATISFIED)  \
+    X(LP2_LINE_VIOLATED) X(LP2_FAILED) X(LP1_DISC_NEGATIVE) X(LP1_PARALLEL_FAIL) X(LP1_PARALLEL_OK) X(LP1_BOUND_RIGHT)    \
+    X(LP1_BOUND_LEFT) X(LP1_EMPTIED) X(LP1_DIR_OPT_RIGHT) X(LP1_DIR_OPT_LEFT) X(LP1_CLAMP_LEFT) X(LP1_CLAMP_RIGHT)        \
+    X(LP1_INTERIOR) X(LP3_ENTERED) X(LP3_ENTERED_WITH_OBST_LINES) X(LP3_LINE_WITHIN_DIST) X(LP3_LINE_BEYOND_DIST)         \
+    X(LP3_PARALLEL_SAME_DIR) X(LP3_PARALLEL_OPPOSITE) X(LP3_PROJECTED) X(LP3_LP2_FAILED_RESTORED) X(LP3_LP2_OK)
+enum {
+#define X(n) BR_##n,
+    ORC_BRANCHES(X)
+#undef X
+    BR__COUNT
+};
+static const char* const g_br_names[BR__COUNT] = {
+#define X(n) #n,
+    ORC_BRANCHES(X)
+#undef X
+};
+static thread_local uint64_t g_br[BR__COUNT];
+#define BR(n) (++g_br[BR_##n])
+struct Capture {                     /* the lines of ONE agent-step (orc_debug_capture selects it) */
+    int arena = -1, agent = -1, armed = 0;
+    int numObst = 0, nObstNb = 0, fail = 0, nl = 0;
+    std::vector<Line> lines;         /* obstacle lines first */
+    std::vector<int> edge;           /* per obstacle LINE: the edge id (processed table) it came from */
+    std::vector<int> tag;            /* per obstacle NEIGHBOUR, in list order: edge id << 8 | the BR_OBST_* outcome */
+};
+static thread_local Capture g_cap;
+static thread_local int g_cur_arena = -1;   /* set by the stepping loops while a capture is armed */
+
 /* App. A.5 LP1 */
 bool lp1(const std::vector<Line>& lines, int lineNo, float radius, V2 opt, bool dirOpt, V2& result) {
     const Line& L = lines[lineNo];
     const float dp = dot(L.point, L.dir);
     const float disc = sqr(dp) + sqr(radius) - absSq(L.point);
-    if (disc < 0.0f) return false;
+    if (disc < 0.0f) { BR(LP1_DISC_NEGATIVE); return false; }
     const float sq = std::sqrt(disc);
     float tLeft = -dp - sq;
     float tRight = -dp + sq;
@@ -236,38 +274,43 @@ bool lp1(const std::vector<Line>& lines, int lineNo, float radius, V2 opt, bool 
         const float den = det(L.dir, lines[j].dir);
         const float num = det(lines[j].dir, L.point - lines[j].point);
         if (std::fabs(den) <= EPS) {
-            if (num < 0.0f) return false;
+            if (num < 0.0f) { BR(LP1_PARALLEL_FAIL); return false; }
+            BR(LP1_PARALLEL_OK);
             continue;
         }
         const float t = num / den;
-        if (den >= 0.0f) tRight = std::min(tRight, t);
-        else tLeft = std::max(tLeft, t);
-        if (tLeft > tRight) return false;
+        if (den >= 0.0f) { BR(LP1_BOUND_RIGHT); tRight = std::min(tRight, t); }
+        else { BR(LP1_BOUND_LEFT); tLeft = std::max(tLeft, t); }
+        if (tLeft > tRight) { BR(LP1_EMPTIED); return false; }
     }
     if (dirOpt) {
-        if (dot(opt, L.dir) > 0.0f) result = L.point + tRight * L.dir;
-        else result = L.point + tLeft * L.dir;
+        if (dot(opt, L.dir) > 0.0f) { BR(LP1_DIR_OPT_RIGHT); result = L.point + tRight * L.dir; }
+        else { BR(LP1_DIR_OPT_LEFT); result = L.point + tLeft * L.dir; }
     } else {
         const float t = dot(L.dir, opt - L.point);
-        if (t < tLeft) result = L.point + tLeft * L.dir;
-        else if (t > tRight) result = L.point + tRight * L.dir;
-        else result = L.point + t * L.dir;
+        if (t < tLeft) { BR(LP1_CLAMP_LEFT); result = L.point + tLeft * L.dir; }
+        else if (t > tRight) { BR(LP1_CLAMP_RIGHT); result = L.point + tRight * L.dir; }
+        else { BR(LP1_INTERIOR); result = L.point + t * L.dir; }
     }
     return true;
 }
 
 /* App. A.5 LP2 */
 int lp2(const std::vector<Line>& lines, float radius, V2 opt, bool dirOpt, V2& result) {
-    if (dirOpt) result = opt * radius;
-    else if (absSq(opt) > sqr(radius)) result = normalize(opt) * radius;
-    else result = opt;
+    if (dirOpt) { BR(LP2_DIR_OPT); result = opt * radius; }
+    else if (absSq(opt) > sqr(radius)) { BR(LP2_OPT_CLAMPED); result = normalize(opt) * radius; }
+    else { BR(LP2_OPT_INSIDE_DISC); result = opt; }
     for (int i = 0; i < (int)lines.size(); ++i) {
         if (det(lines[i].dir, lines[i].point - result) > 0.0f) {
+            BR(LP2_LINE_VIOLATED);
             const V2 tmp = result;
             if (!lp1(lines, i, radius, opt, dirOpt, result)) {
+                BR(LP2_FAILED);
                 result = tmp;
                 return i;
             }
+        } else {
+            BR(LP2_LINE_SATISFIED);
         }
     }
     return (int)lines.size();
@@ -276,17 +319,22 @@ int lp2(const std::vector<Line>& lines, float radius, V2 opt, bool dirOpt, V2& r
 /* App. A.5 LP3 */
 void lp3(const std::vector<Line>& lines, int numObst, int begin, float radius, V2& result) {
     float distance = 0.0f;
+    BR(LP3_ENTERED);
+    if (numObst > 0) BR(LP3_ENTERED_WITH_OBST_LINES);
     for (int i = begin; i < (int)lines.size(); ++i) {
         if (det(lines[i].dir, lines[i].point - result) > distance) {
+            BR(LP3_LINE_BEYOND_DIST);
             static thread_local std::vector<Line> proj;
             proj.assign(lines.begin(), lines.begin() + numObst);
             for (int j = numObst; j < i; ++j) {
                 Line l;
                 const float d = det(lines[i].dir, lines[j].dir);
                 if (std::fabs(d) <= EPS) {
-                    if (dot(lines[i].dir, lines[j].dir) > 0.0f) continue;
+                    if (dot(lines[i].dir, lines[j].dir) > 0.0f) { BR(LP3_PARALLEL_SAME_DIR); continue; }
+                    BR(LP3_PARALLEL_OPPOSITE);
                     l.point = 0.5f * (lines[i].point + lines[j].point);
                 } else {
+                    BR(LP3_PROJECTED);
                     l.point = lines[i].point +
                               (det(lines[j].dir, lines[i].point - lines[j].point) / d) * lines[i].dir;
                 }
@@ -294,9 +342,15 @@ void lp3(const std::vector<Line>& lines, int numObst, int begin, float radius, V
                 proj.push_back(l);
             }
             const V2 tmp = result;
-            if (lp2(proj, radius, mk(-lines[i].dir.y, lines[i].dir.x), true, result) < (int)proj.size())
+            if (lp2(proj, radius, mk(-lines[i].dir.y, lines[i].dir.x), true, result) < (int)proj.size()) {
+                BR(LP3_LP2_FAILED_RESTORED);
                 result = tmp;
+            } else {
+                BR(LP3_LP2_OK);
+            }
             distance = det(lines[i].dir, lines[i].point - result);
+        } else {
+            BR(LP3_LINE_WITHIN_DIST);
         }
     }
 }
@@ -314,9 +368,18 @@ void compute_new_velocity(Arena& a, const std::vector<ObstVertex>& obst, int i, 
     const float invTO = 1.0f / P.timeHorizonObst;
     const float R = P.radius;
 
+    const bool cap = g_cap.armed && g_cap.agent == i && g_cap.arena == g_cur_arena;
+    if (cap) { g_cap.edge.clear(); g_cap.tag.clear(); }
     for (size_t n = 0; n < a.obstNb[i].size(); ++n) {
         int i1 = a.obstNb[i][n].second;
+        const int edge_id = i1;
         int i2 = obst[i1].next;
+        /* the outcome of this neighbour: counted, and recorded when this agent-step is being captured */
+        auto outcome = [&](int br, bool emitted) {
+            ++g_br[br];
+            if (cap) { g_cap.tag.push_back((edge_id << 8) | br); if (emitted) g_cap.edge.push_back(edge_id); }
+        };
+        BR(OBST_EDGE);
         const V2 rp1 = obst[i1].p - pos;
         const V2 rp2 = obst[i2].p - pos;
         bool covered = false;
@@ -327,7 +390,7 @@ void compute_new_velocity(Arena& a, const std::vector<ObstVertex>& obst, int i, 
                 break;
             }
         }
-        if (covered) continue;
+        if (covered) { outcome(BR_OBST_COVERED, false); continue; }
         const float distSq1 = absSq(rp1), distSq2 = absSq(rp2), radiusSq = sqr(R);
         const V2 ov = obst[i2].p - obst[i1].p;
         const float s = dot(-rp1, ov) / absSq(ov);
@@ -338,6 +401,9 @@ void compute_new_velocity(Arena& a, const std::vector<ObstVertex>& obst, int i, 
                 line.point = mk(0.0f, 0.0f);
                 line.dir = normalize(mk(-rp1.y, rp1.x));
                 lines.push_back(line);
+                outcome(BR_OBST_COLL_LEFT_VERTEX, true);
+            } else {
+                outcome(BR_OBST_COLL_LEFT_VERTEX_NONCONVEX, false);
             }
             continue;
         } else if (s > 1.0f && distSq2 <= radiusSq) {
@@ -345,48 +411,59 @@ void compute_new_velocity(Arena& a, const std::vector<ObstVertex>& obst, int i, 
                 line.point = mk(0.0f, 0.0f);
                 line.dir = normalize(mk(-rp2.y, rp2.x));
                 lines.push_back(line);
+                outcome(BR_OBST_COLL_RIGHT_VERTEX, true);
+            } else {
+                outcome(BR_OBST_COLL_RIGHT_VERTEX_SKIPPED, false);
             }
             continue;
         } else if (s >= 0.0f && s < 1.0f && distSqLine <= radiusSq) {
             line.point = mk(0.0f, 0.0f);
             line.dir = -obst[i1].unitDir;
             lines.push_back(line);
+            outcome(BR_OBST_COLL_SEGMENT, true);
             continue;
         }
         V2 leftLeg, rightLeg;
         if (s < 0.0f && distSqLine <= radiusSq) {
-            if (!obst[i1].convex) continue;
+            if (!obst[i1].convex) { outcome(BR_OBST_OBLIQUE_LEFT_NONCONVEX, false); continue; }
+            BR(OBST_OBLIQUE_LEFT);
             i2 = i1;
             const float leg1 = std::sqrt(distSq1 - radiusSq);
             leftLeg = vdiv(mk(rp1.x * leg1 - rp1.y * R, rp1.x * R + rp1.y * leg1), distSq1);
             rightLeg = vdiv(mk(rp1.x * leg1 + rp1.y * R, -rp1.x * R + rp1.y * leg1), distSq1);
         } else if (s > 1.0f && distSqLine <= radiusSq) {
-            if (!obst[i2].convex) continue;
+            if (!obst[i2].convex) { outcome(BR_OBST_OBLIQUE_RIGHT_NONCONVEX, false); continue; }
+            BR(OBST_OBLIQUE_RIGHT);
             i1 = i2;
             const float leg2 = std::sqrt(distSq2 - radiusSq);
             leftLeg = vdiv(mk(rp2.x * leg2 - rp2.y * R, rp2.x * R + rp2.y * leg2), distSq2);
             rightLeg = vdiv(mk(rp2.x * leg2 + rp2.y * R, -rp2.x * R + rp2.y * leg2), distSq2);
         } else {
+            BR(OBST_LEGS_USUAL);
             if (obst[i1].convex) {
                 const float leg1 = std::sqrt(distSq1 - radiusSq);
                 leftLeg = vdiv(mk(rp1.x * leg1 - rp1.y * R, rp1.x * R + rp1.y * leg1), distSq1);
             } else {
+                BR(OBST_LEFT_LEG_NONCONVEX);
                 leftLeg = -obst[i1].unitDir;
             }
             if (obst[i2].convex) {
                 const float leg2 = std::sqrt(distSq2 - radiusSq);
                 rightLeg = vdiv(mk(rp2.x * leg2 + rp2.y * R, -rp2.x * R + rp2.y * leg2), distSq2);
             } else {
+                BR(OBST_RIGHT_LEG_NONCONVEX);
                 rightLeg = obst[i1].unitDir;
             }
         }
         const int leftNb = obst[i1].prev;
         bool leftForeign = false, rightForeign = false;
         if (obst[i1].convex && det(leftLeg, -obst[leftNb].unitDir) >= 0.0f) {
+            BR(OBST_LEFT_LEG_FOREIGN);
             leftLeg = -obst[leftNb].unitDir;
             leftForeign = true;
         }
         if (obst[i2].convex && det(rightLeg, obst[i2].unitDir) <= 0.0f) {
+            BR(OBST_RIGHT_LEG_FOREIGN);
             rightLeg = obst[i2].unitDir;
             rightForeign = true;
         }
@@ -402,12 +479,14 @@ void compute_new_velocity(Arena& a, const std::vector<ObstVertex>& obst, int i, 
             line.dir = mk(unitW.y, -unitW.x);
             line.point = leftCut + R * invTO * unitW;
             lines.push_back(line);
+            outcome(BR_OBST_PROJ_LEFT_CIRCLE, true);
             continue;
         } else if (t > 1.0f && tRight < 0.0f) {
             const V2 unitW = normalize(vel - rightCut);
             line.dir = mk(unitW.y, -unitW.x);
             line.point = rightCut + R * invTO * unitW;
             lines.push_back(line);
+            outcome(BR_OBST_PROJ_RIGHT_CIRCLE, true);
             continue;
         }
         const float dCut = (t < 0.0f || t > 1.0f || same) ? FINF : absSq(vel - (leftCut + t * cutVec));
@@ -417,18 +496,21 @@ void compute_new_velocity(Arena& a, const std::vector<ObstVertex>& obst, int i, 
             line.dir = -obst[i1].unitDir;
             line.point = leftCut + R * invTO * mk(-line.dir.y, line.dir.x);
             lines.push_back(line);
+            outcome(BR_OBST_PROJ_CUTOFF, true);
             continue;
         } else if (dLeft <= dRight) {
-            if (leftForeign) continue;
+            if (leftForeign) { outcome(BR_OBST_PROJ_LEFT_LEG_FOREIGN_SKIPPED, false); continue; }
             line.dir = leftLeg;
             line.point = leftCut + R * invTO * mk(-line.dir.y, line.dir.x);
             lines.push_back(line);
+            outcome(BR_OBST_PROJ_LEFT_LEG, true);
             continue;
         } else {
-            if (rightForeign) continue;
+            if (rightForeign) { outcome(BR_OBST_PROJ_RIGHT_LEG_FOREIGN_SKIPPED, false); continue; }
             line.dir = -rightLeg;
             line.point = rightCut + R * invTO * mk(-line.dir.y, line.dir.x);
             lines.push_back(line);
+            outcome(BR_OBST_PROJ_RIGHT_LEG, true);
         }
     }
     const int numObstLines = (int)lines.size();
@@ -448,20 +530,25 @@ void compute_new_velocity(Arena& a, const std::vector<ObstVertex>& obst, int i, 
             const float wLenSq = absSq(w);
             const float dp1 = dot(w, rp);
             if (dp1 < 0.0f && sqr(dp1) > crSq * wLenSq) {
+                BR(AGENT_CUTOFF_CIRCLE);
                 const float wLen = std::sqrt(wLenSq);
                 const V2 unitW = vdiv(w, wLen);
                 line.dir = mk(unitW.y, -unitW.x);
                 u = (cr * invT - wLen) * unitW;
             } else {
                 const float leg = std::sqrt(distSq - crSq);
-                if (det(rp, w) > 0.0f)
+                if (det(rp, w) > 0.0f) {
+                    BR(AGENT_LEG_LEFT);
                     line.dir = vdiv(mk(rp.x * leg - rp.y * cr, rp.x * cr + rp.y * leg), distSq);
-                else
+                } else {
+                    BR(AGENT_LEG_RIGHT);
                     line.dir = -vdiv(mk(rp.x * leg + rp.y * cr, -rp.x * cr + rp.y * leg), distSq);
+                }
                 const float dp2 = dot(rv, line.dir);
                 u = dp2 * line.dir - rv;
             }
         } else {
+            BR(AGENT_COLLISION);
             const float invDt = 1.0f / timeStep;
             const V2 w = rv - invDt * rp;
             const float wLen = vabs(w);
@@ -474,6 +561,10 @@ void compute_new_velocity(Arena& a, const std::vector<ObstVertex>& obst, int i, 
     }
     V2 nv = mk(0.0f, 0.0f);
     const int fail = lp2(lines, P.maxSpeed, a.pref[i], false, nv);
+    if (cap) {
+        g_cap.lines = lines; g_cap.numObst = numObstLines; g_cap.nObstNb = (int)a.obstNb[i].size(); g_cap.fail = fail;
+        g_cap.nl = (int)lines.size(); g_cap.armed = 2;
+    }
     g_dbg[0] += 1;
     if (fail < (int)lines.size()) { g_dbg[1] += 1; g_dbg[2] += lines.size() - fail; lp3(lines, numObstLines, fail, P.maxSpeed, nv); }
     a.newVel[i] = nv;
@@ -967,6 +1058,7 @@ void arena_step(Env& e, int a, const float* actions, uint32_t flags, int prec) {
             ar.pref[i] = mk((float)lx, (float)ly);
         }
     }
+    g_cur_arena = a;   /* (read by an armed capture only) */
     do_step(ar, e.tab(a), c.time_step, c.max_obst_neighbors, &e.st[a].obst_overflow);
     e.st[a].agent_steps += (uint64_t)N;
     if (flags & ORC_F_STATS) arena_collisions(e, a);
@@ -1029,6 +1121,7 @@ void arena_alan_step(Env& e, int a, const double* u, uint32_t flags, int prec) {
         e.rl64[2 * q] = lx; e.rl64[2 * q + 1] = ly;
         ar.pref[i] = mk((float)lx, (float)ly);                                        /* :598 */
     }
+    g_cur_arena = a;   /* (read by an armed capture only) */
     do_step(ar, e.tab(a), c.time_step, c.max_obst_neighbors, &e.st[a].obst_overflow);  /* :601 */
     e.st[a].agent_steps += (uint64_t)N;
     if (flags & ORC_F_STATS) arena_collisions(e, a);
@@ -1533,6 +1626,7 @@ int orc_sim_add_obstacle(void* sim, const float* xy, int32_t n) { return add_pol
 void orc_sim_process_obstacles(void* sim) { process_obstacles(((Sim*)sim)->obst); }
 void orc_sim_do_step(void* sim) {
     Sim* s = (Sim*)sim;
+    g_cur_arena = 0;   /* (a simulator is one arena: orc_debug_capture(0, agent)) */
     do_step(s->ar, s->obst, s->timeStep, std::numeric_limits<int>::max(), nullptr);
 }
 int orc_sim_num_agents(void* sim) { return ((Sim*)sim)->ar.n(); }
@@ -1590,6 +1684,27 @@ void orc_comp_laser_f32(const float* ray_ends, const float* segs, int32_t m, con
     comp_laser<float>(ray_ends, (const Seg<float>*)(const void*)segs, m, (float)ox, (float)(-oy), out);
 }
 void orc_debug_counters(uint64_t* out4) { for (int i = 0; i < 4; ++i) out4[i] = g_dbg[i]; }
+/* branch counters of the CALLING thread (serial stepping: tests), names in the same order */
+int orc_debug_branch_count(void) { return BR__COUNT; }
+const char* orc_debug_branch_name(int k) { return (k >= 0 && k < BR__COUNT) ? g_br_names[k] : ""; }
+void orc_debug_branches(uint64_t* out, int n) { for (int i = 0; i < n && i < BR__COUNT; ++i) out[i] = g_br[i]; }
+void orc_debug_branches_reset(void) { for (int i = 0; i < BR__COUNT; ++i) g_br[i] = 0; }
+/* capture the ORCA lines of agent `agent` of arena `arena` (local index) during the NEXT serial step on this thread */
+void orc_debug_capture(int arena, int agent) { g_cap.arena = arena; g_cap.agent = agent; g_cap.armed = (arena >= 0) ? 1 : 0; }
+/* -> number of lines (obstacle lines first), or -1 if nothing was captured.  lines4: [cap][4] = point.x, point.y, dir.x, dir.y;
+ * line_edge: [cap] edge id of each OBSTACLE line; nb_tag: [cap] per obstacle neighbour, edge id << 8 | branch index;
+ * info4: numObstLines, obstacle neighbours, the line LP2 failed at (= lines: feasible), lines */
+int orc_debug_captured(float* lines4, int* line_edge, int* nb_tag, int cap, int* info4) {
+    if (g_cap.armed != 2) return -1;
+    for (int k = 0; k < g_cap.nl && k < cap; ++k) {
+        lines4[4 * k] = g_cap.lines[k].point.x; lines4[4 * k + 1] = g_cap.lines[k].point.y;
+        lines4[4 * k + 2] = g_cap.lines[k].dir.x; lines4[4 * k + 3] = g_cap.lines[k].dir.y;
+    }
+    for (int k = 0; k < (int)g_cap.edge.size() && k < cap; ++k) line_edge[k] = g_cap.edge[k];
+    for (int k = 0; k < (int)g_cap.tag.size() && k < cap; ++k) nb_tag[k] = g_cap.tag[k];
+    info4[0] = g_cap.numObst; info4[1] = (int)g_cap.tag.size(); info4[2] = g_cap.fail; info4[3] = g_cap.nl;
+    return g_cap.nl;
+}
 void orc_sincos64(double a, double* s, double* c) { sincos64(a, s, c); }
 double orc_exp64(double x) { return exp64(x); }
 void orc_pref_dir64(float px, float py, double gx, double gy, double* out2) { pref_dir64(px, py, gx, gy, &out2[0], &out2[1]); }

@@ -11,6 +11,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libca_oracle.so")
+# CA_ORACLE_SANITIZED=1 (tests/test_oracle_sanitized.py, a child interpreter started under LD_PRELOAD=libasan): load the
+# -fsanitize=address,undefined build of the same source (make -C oracle asan) instead
+_SANITIZED = os.environ.get("CA_ORACLE_SANITIZED") == "1"
+if _SANITIZED:
+    _LIB_PATH = os.path.join(_HERE, "libca_oracle_asan.so")
 
 OBS_DIM = 64
 DONE_XLESS, DONE_GOAL, DONE_REGOAL = 0, 1, 2
@@ -53,7 +58,7 @@ def build(force=False):
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(s) for s in src)):
         return _LIB_PATH
-    subprocess.check_call(["make", "-s", "-C", _HERE, "libca_oracle.so"])
+    subprocess.check_call(["make", "-s", "-C", _HERE, "asan" if _SANITIZED else "libca_oracle.so"])
     return _LIB_PATH
 
 
@@ -112,6 +117,11 @@ def lib():
     L.orc_sincos64.argtypes = [C.c_double, vp, vp]
     L.orc_pref_dir64.argtypes = [f32, f32, C.c_double, C.c_double, vp]
     L.orc_philox4x32.argtypes = [u32] * 6 + [vp]
+    L.orc_debug_branch_name.restype = C.c_char_p
+    L.orc_debug_branch_name.argtypes = [i32]
+    L.orc_debug_branches.argtypes = [vp, i32]
+    L.orc_debug_capture.argtypes = [i32, i32]
+    L.orc_debug_captured.argtypes = [vp, vp, vp, i32, vp]
     L.orc_ray_table.argtypes = [C.c_double, vp]
     L.orc_octagon_table.argtypes = [C.c_double, vp]
     _lib = L
@@ -354,3 +364,39 @@ def octagon_table(radius):
     out = np.zeros(32, np.float64)
     lib().orc_octagon_table(float(radius), _ptr(out))
     return out.reshape(8, 4)
+
+
+# ---- diagnostics (tests/test_oracle_orca_definition.py): branch counters and captured ORCA lines of the calling thread ----
+def branch_names():
+    L = lib()
+    return [L.orc_debug_branch_name(k).decode() for k in range(L.orc_debug_branch_count())]
+
+
+def branch_counts(reset=False):
+    """{branch name: times taken} on this thread since the last reset (SURVEY App. A.3 / A.4 / A.5 branch by branch)."""
+    L = lib()
+    n = L.orc_debug_branch_count()
+    out = np.zeros(n, np.uint64)
+    L.orc_debug_branches(_ptr(out), n)
+    if reset:
+        L.orc_debug_branches_reset()
+    return dict(zip(branch_names(), (int(v) for v in out)))
+
+
+def capture_next(arena, agent):
+    """Record the ORCA lines of `agent` of `arena` during the next serial step on this thread (a PyRVOSimulator is arena 0)."""
+    lib().orc_debug_capture(int(arena), int(agent))
+
+
+def captured(cap=64):
+    """dict(lines [n,4] = point.x, point.y, dir.x, dir.y (obstacle lines first), n_obst_lines, line_edge [n_obst_lines],
+    nb_edge / nb_branch per obstacle neighbour in list order, fail = the line LP2 failed at (n: feasible)), or None."""
+    L = lib()
+    lines = np.zeros((cap, 4), np.float32)
+    edge, tag, info = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(4, np.int32)
+    n = L.orc_debug_captured(_ptr(lines), _ptr(edge), _ptr(tag), cap, _ptr(info))
+    if n < 0:
+        return None
+    names = branch_names()
+    return dict(lines=lines[:n].copy(), n_obst_lines=int(info[0]), line_edge=edge[:info[0]].copy(),
+                nb_edge=(tag[:info[1]] >> 8), nb_branch=[names[t & 0xFF] for t in tag[:info[1]]], fail=int(info[2]))

@@ -42,12 +42,12 @@ def make_oracle(A, N, scenario, params, seed=0, arena_offset=0, max_obst_neighbo
 
 
 def make_gpu(A, N, scenario, params, seed=0, arena_offset=0, max_obst_neighbors=None, use_torch=False,
-             polys=None):
+             polys=None, **kw):
     from collision_avoidance_amd.vec_env import VecCollisionAvoidanceEnv
     return VecCollisionAvoidanceEnv(A, N, scenario=scenario, params=params, seed=seed,
                                     arena_offset=arena_offset, max_obst_neighbors=max_obst_neighbors,
                                     use_torch=use_torch,
-                                    obstacles="scenario" if polys is None else polys)
+                                    obstacles="scenario" if polys is None else polys, **kw)
 
 
 def _eq(a, b, what):
@@ -146,3 +146,8 @@ class OracleVec(object):
 
     def close(self):
         pass
+
+
+def _lib_fld(name):
+    from collision_avoidance_amd import _lib
+    return getattr(_lib, "FLD_" + name)

@@ -122,7 +122,7 @@ def test_gpu_replays_reference_alan_online_runs(golden_dir, ci):
     c = load_case(golden_dir, ci)
 
     def make(n, scen, p):
-        return H.make_gpu(1, n, scen, p, max_obst_neighbors=8)
+        return H.make_gpu(1, n, scen, p, max_obst_neighbors=16)
     env, n, p = setup_env(make, c, lambda e, f, v: e.set(f, v), _lib)
     env.alan_configure(c["actions"])
     steps = c["u"].shape[0]
@@ -218,7 +218,7 @@ def test_gpu_replays_reference_orca_episode_loop(golden_dir, ci):
     c = load_orca_case(golden_dir, ci)
 
     def make(n, scen, p):
-        return H.make_gpu(1, n, scen, p, max_obst_neighbors=8)
+        return H.make_gpu(1, n, scen, p, max_obst_neighbors=16)
     env, n, p = setup_env(make, c, lambda e, f, v: e.set(f, v), _lib)
     env.set(_lib.FLD_PREF_X, c["pref0"][:, 0]); env.set(_lib.FLD_PREF_Y, c["pref0"][:, 1])
     replay_orca_episode(env, c, _lib, lambda e: e.orca_step(), lambda e, f: e.get(f))
@@ -234,7 +234,7 @@ def test_gpu_replays_reference_episodes_that_finish(golden_dir, ci):
     c = load_finished_case(golden_dir, ci)
 
     def make(n, scen, p):
-        return H.make_gpu(1, n, scen, p, max_obst_neighbors=8)
+        return H.make_gpu(1, n, scen, p, max_obst_neighbors=16)
     env, n, p = setup_env(make, c, lambda e, f, v: e.set(f, v), _lib)
     env.set(_lib.FLD_PREF_X, c["pref0"][:, 0]); env.set(_lib.FLD_PREF_Y, c["pref0"][:, 1])
     if int(c["mode"]) == 1:

@@ -320,7 +320,7 @@ def _golden_replay_gpu(golden_dir, name):
         return int(bad.sum())
     g = np.load(os.path.join(golden_dir, name))
     n = int(g["n_agents"])
-    env = H.make_gpu(1, n, "doorway", scenarios.env_params(), max_obst_neighbors=8)
+    env = H.make_gpu(1, n, "doorway", scenarios.env_params(), max_obst_neighbors=16)
     assert (env.get(_lib.FLD_GOAL2_X) == -10.0).all() and (env.get(_lib.FLD_GOAL2_Y) == 5.0).all()   # env.py:361: the doorway
     env.set(_lib.FLD_POS_X, g["pos0"][:, 0]); env.set(_lib.FLD_POS_Y, g["pos0"][:, 1])               # world's own retarget
     env.set(_lib.FLD_VEL_X, g["vel0"][:, 0]); env.set(_lib.FLD_VEL_Y, g["vel0"][:, 1])
@@ -383,8 +383,8 @@ def test_gpu_autoreset_at_the_recorded_end_of_an_episode(golden_dir, name):
     g = np.load(os.path.join(golden_dir, name))
     n = int(g["n_agents"])
     r = int(g["reset_steps"][0])
-    env = H.make_gpu(1, n, "doorway", scenarios.env_params(), max_obst_neighbors=8, seed=3)
-    orc = H.make_oracle(1, n, "doorway", scenarios.env_params(), max_obst_neighbors=8, seed=3)
+    env = H.make_gpu(1, n, "doorway", scenarios.env_params(), max_obst_neighbors=16, seed=3)
+    orc = H.make_oracle(1, n, "doorway", scenarios.env_params(), max_obst_neighbors=16, seed=3)
     for e, F in ((env, _lib), (orc, o)):
         for f, v in (("POS_X", g["pos0"][:, 0]), ("POS_Y", g["pos0"][:, 1]), ("VEL_X", g["vel0"][:, 0]), ("VEL_Y", g["vel0"][:, 1]),
                      ("PREF_X", g["pref0"][:, 0]), ("PREF_Y", g["pref0"][:, 1]), ("GOAL_X", g["tgt0"][:, 0]), ("GOAL_Y", g["tgt0"][:, 1])):
@@ -609,7 +609,7 @@ def test_plain_c_client_of_the_abi(tmp_path):
         for b in np.ascontiguousarray(a).view(np.uint8).reshape(-1).tolist():
             h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
         return h
-    env = H.make_gpu(A, N, "doorway", H.scenario_params("doorway", N), seed=7, max_obst_neighbors=8)
+    env = H.make_gpu(A, N, "doorway", H.scenario_params("doorway", N), seed=7, max_obst_neighbors=16)
     env.reset()
     lcg = 12345
     for s in range(steps):

@@ -56,7 +56,7 @@ def test_online_step_matches_reference(golden_dir, ci):
     c = load_case(golden_dir, ci)
 
     def make(n, scen, p):
-        e = o.OracleEnv(o.make_config(n_arenas=1, n_agents=n, max_obst_neighbors=8, **p))
+        e = o.OracleEnv(o.make_config(n_arenas=1, n_agents=n, max_obst_neighbors=16, **p))
         e.set_obstacles(scenarios.obstacles(scen, n))
         e.init_scenario(scenarios.SCENARIO_IDS[scen])
         return e
@@ -164,7 +164,7 @@ def test_plain_orca_episode_matches_reference(golden_dir, ci):
     c = load_orca_case(golden_dir, ci)
 
     def make(n, scen, p):
-        e = o.OracleEnv(o.make_config(n_arenas=1, n_agents=n, max_obst_neighbors=8, **p))
+        e = o.OracleEnv(o.make_config(n_arenas=1, n_agents=n, max_obst_neighbors=16, **p))
         e.set_obstacles(scenarios.obstacles(scen, n))
         e.init_scenario(scenarios.SCENARIO_IDS[scen])
         return e

@@ -169,7 +169,7 @@ def test_process_obstacles_cuts_crossing_edges():
     and appends the cut points to the vertex table."""
     from collision_avoidance_amd import scenarios
     p = scenarios.env_params()
-    e = o.OracleEnv(o.make_config(n_arenas=1, n_agents=2, max_obst_neighbors=8, **p))
+    e = o.OracleEnv(o.make_config(n_arenas=1, n_agents=2, max_obst_neighbors=16, **p))
     polys = scenarios.obstacles("doorway", 2)
     e.set_obstacles(polys)
     t = e.obstacle_table()
@@ -182,7 +182,7 @@ def test_process_obstacles_cuts_crossing_edges():
     # a convex outer wall alone is never cut; every scenario keeps closed rings and its total wall length
     for scen, n in (("crowd", 16), ("circle", 8), ("incoming", 10), ("congested", 12), ("blocks", 8), ("deadlock", 10)):
         polys = scenarios.obstacles(scen, n)
-        e = o.OracleEnv(o.make_config(n_arenas=1, n_agents=n, max_obst_neighbors=8, **scenarios.alan_params(n, scen)))
+        e = o.OracleEnv(o.make_config(n_arenas=1, n_agents=n, max_obst_neighbors=16, **scenarios.alan_params(n, scen)))
         e.set_obstacles(polys)
         t = e.obstacle_table(cap=512)
         n0 = sum(len(q) for q in polys)

@@ -81,7 +81,7 @@ def test_oracle_replays_reference_block_worlds_as_one_batch(golden_dir):
     assert len({tuple(w["obst"][1].ravel()) for w in worlds}) == len(worlds)     # the reference drew different blocks
 
     def make(A, n, p, polys):
-        e = o.OracleEnv(o.make_config(n_arenas=A, n_agents=n, max_obst_neighbors=8, **p))
+        e = o.OracleEnv(o.make_config(n_arenas=A, n_agents=n, max_obst_neighbors=16, **p))
         e.set_obstacles_per_arena(polys)
         e.init_scenario(o.SCN_BLOCKS)
         return e
@@ -116,7 +116,7 @@ def test_per_arena_obstacle_golden_worlds_on_gpu(golden_dir):
     worlds, n = load_worlds(golden_dir)
 
     def make(A, n, p, polys):
-        return H.make_gpu(A, n, "blocks", p, max_obst_neighbors=8, polys=dict(per_arena=polys))
+        return H.make_gpu(A, n, "blocks", p, max_obst_neighbors=16, polys=dict(per_arena=polys))
     env, p = batch_of_golden_worlds(make, worlds, n, lambda e, f, v: e.set(f, v), _lib)
     for a, w in enumerate(worlds):
         np.testing.assert_array_equal(env.obstacle_table(arena=a)["verts"][:20], w["obst"].reshape(20, 2))
@@ -174,8 +174,10 @@ def test_per_arena_obstacle_ragged_and_wide_tables():
     worlds = [[], [border],
               [border, [(2.0, 0.0), (2.5, 0.0), (2.5, 2.4), (2.0, 2.4)], [(2.0, 3.6), (2.5, 3.6), (2.5, E), (2.0, E)]],
               [border] + _squares(9, 0.3, 0.3, 0.65, 0.2)]
-    g = H.make_gpu(4, N, "crowd", p, seed=8, polys=dict(per_arena=worlds), max_obst_neighbors=8)
-    e = H.make_oracle(4, N, "crowd", p, seed=8, polys=dict(per_arena=worlds), max_obst_neighbors=8)
+    # (a grid of squares puts up to 59 edges within range of an agent: more than any list holds -- accepted here on purpose, the
+    # oracle truncates the same way; without the opt-in the step calls fail loudly: tests/test_gpu_overflow.py)
+    g = H.make_gpu(4, N, "crowd", p, seed=8, polys=dict(per_arena=worlds), max_obst_neighbors=16, allow_obst_overflow=True)
+    e = H.make_oracle(4, N, "crowd", p, seed=8, polys=dict(per_arena=worlds), max_obst_neighbors=16)
     assert [g.obstacle_table(arena=a)["verts"].shape[0] for a in range(4)][:2] == [0, 4]
     assert g.obstacle_table(arena=3)["verts"].shape[0] >= 4 + 81 * 4
     for a in range(4):
