@@ -294,16 +294,34 @@ def test_autoreset_and_explicit_reset():
 
 
 def test_sharding_invariance():
-    """Arena g computes the same thing whichever shard owns it (RNG keyed by global arena id)."""
+    """Arena g computes the same thing whichever shard owns it (every draw keyed by the GLOBAL arena id; run_rllib.py:108 replicates
+    environments over workers the same way): a handle of 8 arenas against two handles of 4 -- ORCA rollout, then full steps with
+    the same actions, statistics and auto-reset on -- compared field by field as bit patterns: the whole state, the neighbour
+    lists, reward, observation and the per-arena counters."""
+    from collision_avoidance_amd import _lib
     N = 16
     p = scenarios.bench_params(N, 1.5, 5)
     whole = H.make_gpu(8, N, "crowd", p, seed=4)
     parts = [H.make_gpu(4, N, "crowd", p, seed=4, arena_offset=off) for off in (0, 4)]
-    for e in [whole] + parts:
-        e.rollout(700)
-    from collision_avoidance_amd import _lib
-    for f in (_lib.FLD_POS_X, _lib.FLD_POS_Y, _lib.FLD_GOAL_X, _lib.FLD_REGOAL_COUNT):
-        np.testing.assert_array_equal(whole.get(f), np.concatenate([e.get(f) for e in parts]))
+    rng = np.random.RandomState(11)
+    acts = rng.uniform(-1, 1, (40, 8, N)).astype(np.float32)
+    for e, sl in [(whole, slice(0, 8)), (parts[0], slice(0, 4)), (parts[1], slice(4, 8))]:
+        e.rollout(700, stats=True)
+        for t in range(40):
+            e.step(acts[t, sl], stats=True, autoreset=True)
+    names = ["POS_X", "POS_Y", "VEL_X", "VEL_Y", "PREF_X", "PREF_Y", "GOAL_X", "GOAL_Y", "GOAL2_X", "GOAL2_Y", "REWARD", "AGENT_DONE",
+             "ARRIVE_STEP", "NB_COUNT", "OBST_COUNT", "OBST_IDX", "OBS", "STEP_COUNT", "ARENA_DONE", "EPISODE", "REGOAL_COUNT", "ARENA_STATS"]
+    for nm in names:
+        f = getattr(_lib, "FLD_" + nm)
+        H._eq(whole.get(f), np.concatenate([e.get(f) for e in parts]), "sharding " + nm)
+    wc, wi = whole.neighbor_lists()                      # (entries beyond the count are not defined)
+    pi = np.concatenate([e.neighbor_lists()[1] for e in parts])
+    m = np.arange(wi.shape[2])[None, None, :] < wc[:, :, None]
+    H._eq(np.where(m, wi, -1), np.where(m, pi, -1), "sharding NB_IDX")
+    tot = whole.stats()
+    for k in ("agent_steps", "episodes", "collisions", "obst_collisions", "goals_reached", "obst_overflow"):
+        assert tot[k] == sum(e.stats()[k] for e in parts), k
+    assert tot["goals_reached"] > 0 and tot["agent_steps"] == 8 * N * 740
     for e in [whole] + parts:
         e.close()
 
