@@ -406,18 +406,6 @@ def main():
         torch.cuda.synchronize()
         per_step_calls = A * N * n2 / (time.perf_counter() - t1)
         steps_run += n2
-    # Short timed regions (the driver's --steps 20) bracket only two launches per kernel: 64 more steps AFTER the region, every launch
-    # sampled, give the same per-kernel means from a sample the reader can trust (reported beside the region's own; `roofline`
-    # stays on the region's).  They are steps of the same run: the oracle replay below covers them too.
-    after_region = None
-    if args.steps < 200 and chunk == 1:
-        env.profile(1)
-        for i in range(64):
-            one_step(steps_run + i)
-        torch.cuda.synchronize()
-        after_region = {k: {"launches": v[0], "ms": round(v[1], 5)} for k, v in env.profile_read().items() if v[0] > 0}
-        env.profile(0)
-        steps_run += 64
     verified = None
     if args.verify > 0:
         # outside the timed region; a checker that cannot run (no oracle library, an exception inside it) must not discard a
@@ -542,7 +530,6 @@ def main():
             "kernels_ms": dict({k: round(v, 5) for k, v in kms_of.items()}, sum=round(sum(kms_of.values()), 5),
                                wall_per_step=dt / args.steps * 1e3,
                                sampled_launches={k: v[0] for k, v in ktimes.items() if v[0] > 0},
-                               after_region_every_launch_sampled=after_region,
                                note="mean duration of the SAMPLED launches (start / stop events on their own dispatch: such a launch is "
                                     "serialised against its neighbours); unsampled launches overlap their ramp-up and drain with the "
                                     "neighbouring kernels by a few tenths of a microsecond, so wall_per_step may lie slightly below the sum"),

@@ -52,8 +52,7 @@ def test_gloo_ranks_drive_the_hip_library(world, arenas):
     # --verify under --gpus N: EVERY rank replayed arenas of its own global range through the oracle and its verdict came
     # through the one all_gather; the blocks differ by the ranks' arena offsets
     v = job["verified"]
-    assert v["bit_exact"] and v["ranks_verified"] == world and v["steps"] == STEPS + WARM + 64, v    # (+ the 64 every-launch-sampled steps a short run appends)
-    assert job["kernels_ms"]["after_region_every_launch_sampled"]["step_kernel"]["launches"] == 64
+    assert v["bit_exact"] and v["ranks_verified"] == world and v["steps"] == STEPS + WARM, v
     assert [r["verified"] for r in job["ranks"]] == [1] * world
     a0 = [r["verify_arena0"] for r in job["ranks"]]
     assert all(r * arenas <= a < (r + 1) * arenas for r, a in enumerate(a0)), a0
