@@ -387,7 +387,7 @@ def test_gpu_replays_reference_env_loop_golden(golden_dir, name):
     recorded with the oracle's ORCA standing in for the absent rvo2 module (tests/golden/make_golden.py), so this pins the
     Python loops and the laser observation, not the ORCA solver itself."""
     bad, tot = _golden_replay_gpu(golden_dir, name)
-    assert bad <= max(2, tot // 500), (bad, tot)
+    assert bad <= 2, (bad, tot)        # (observed: 0 of ~46 000 rays; each one that differs must be within FLIP_MARGIN of flipping: count_bad)
 
 
 @pytest.mark.parametrize("name", ["env_doorway_n6_episode.npz", "env_doorway_n4_all_done.npz"])
