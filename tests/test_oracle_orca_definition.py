@@ -640,3 +640,43 @@ def test_every_branch_by_value():
     assert n["infeasible, obstacle half-planes hard"] >= 150 and n["infeasible, agents only"] >= 150
     assert n["infeasible, obstacle half-planes hard: optimum unique"] >= 100
     assert n["scenes compared"] >= 0.95 * n_scenes
+
+
+def test_agent_neighbour_lists_are_the_k_nearest_in_range():
+    """App. A.2 by value: the ORCA neighbours of an agent are the maxNeighbors nearest agents strictly inside neighborDist,
+    nearest first -- from fp64 distances, on crowds where the list is cut by K, by the range, or by neither (scenes with two
+    candidates closer together than 1e-6 in squared distance around a cut are skipped: fp32 may order them either way; exact
+    ties resolve to the lower index, tests/test_oracle_orca.py)."""
+    rng = np.random.RandomState(31)
+    checked = by_k = by_range = 0
+    for _ in range(400):
+        n = rng.randint(3, 40)
+        K = rng.randint(1, 12)
+        nd = rng.uniform(1.0, 6.0)
+        pos = rng.uniform(0, 2.0 + 0.35 * n, (n, 2)).astype(np.float32)
+        s = PyRVOSimulator(timeStep=DT, neighborDist=float(nd), maxNeighbors=int(K), timeHorizon=TAU, timeHorizonObst=TAU,
+                           radius=R, maxSpeed=VMAX)
+        for i in range(n):
+            s.addAgent((float(pos[i, 0]), float(pos[i, 1])))
+        s.doStep()
+        p64 = pos.astype(np.float64)
+        nd32 = float(np.float32(nd))
+        for i in range(n):
+            d2 = np.sum((p64 - p64[i]) ** 2, axis=1)
+            d2[i] = np.inf
+            order = np.argsort(d2, kind="stable")
+            inside = [int(j) for j in order if d2[j] < nd32 * nd32]
+            exp = inside[:K]
+            # margins: the K-th / (K+1)-th candidates, the range, and neighbouring entries of the list
+            edge = []
+            if len(inside) > K:
+                edge.append(d2[inside[K]] - d2[inside[K - 1]])
+            edge += [abs(d2[j] - nd32 * nd32) for j in order[:len(inside) + 1] if np.isfinite(d2[j])]
+            edge += [d2[exp[k + 1]] - d2[exp[k]] for k in range(len(exp) - 1)]
+            if edge and min(edge) < 1e-5:
+                continue
+            got = [s.getAgentAgentNeighbor(i, k) for k in range(s.getAgentNumAgentNeighbors(i))]
+            assert got == exp, (n, K, nd, i, got, exp)
+            checked += 1
+            by_k += int(len(inside) > K); by_range += int(len(inside) < min(K, n - 1))
+    assert checked > 5000 and by_k > 1000 and by_range > 1000, (checked, by_k, by_range)
